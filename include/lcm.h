@@ -1,0 +1,186 @@
+/*
+ * lcm.h — C ABI of the MI355X loop-closure descriptor matcher ("lcm").
+ *
+ * This is the drop-in boundary for the ORB / Hamming hot path that the reference project
+ * F-Fer/SLAM-Loop-Closing declares in include/loop_closing.hpp but delegates to
+ * cv::BFMatcher(NORM_HAMMING).  Every entry point cites the reference interface it replaces
+ * (paths are relative to the reference checkout):
+ *
+ *   lcm_match_pair        <- the `matcher_->match(desc1, desc2, matches)` call that
+ *                            LoopClosingSystem::matchFeatures makes (include/loop_closing.hpp:40,73)
+ *   lcm_match_features    <- LoopClosingSystem::matchFeatures incl. the "2 x minimum distance"
+ *                            filter (include/loop_closing.hpp:40, README.md:116-117)
+ *   lcm_db_append*        <- `frames_.push_back(frame)` inside processFrame
+ *                            (include/loop_closing.hpp:34,69) — the stored-frame descriptor database
+ *   lcm_query_scores      <- the per-stored-frame loop inside detectLoops
+ *                            (include/loop_closing.hpp:48, README.md:121-126)
+ *   lcm_detect_loops      <- LoopClosingSystem::detectLoops (include/loop_closing.hpp:48)
+ *   lcm_all_vs_all        <- the O(N^2) "every frame against every frame >= gap ago" search, whose only
+ *                            executed analogue in the tree is src/main.cpp:1375-1388
+ *   lcm_loop_candidate    <- struct LoopCandidate (include/loop_closing.hpp:22-27), same field order
+ *   lcm_dmatch            <- cv::DMatch as consumed at src/main.cpp:551-555 (queryIdx, trainIdx, imgIdx, distance)
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no C++/torch/OpenCV types; caller owns every host buffer;
+ *     the library owns device memory behind the opaque lcm_handle.
+ *   - a descriptor is 32 bytes (256 bits); descriptor matrices are row-major, n rows x 32 bytes,
+ *     contiguous — exactly `cv::Mat(CV_8UC1, rows=n, cols=32).ptr<uint8_t>()`.
+ *   - every function returns an lcm_status (0 = OK, negative = error); nothing throws across the
+ *     boundary; lcm_last_error() gives the message of the calling thread's last failure.
+ *   - there is NO CPU fallback: without a usable HIP device lcm_create fails with
+ *     LCM_ERR_NO_DEVICE.  The CPU restatement under oracle/ is test infrastructure only.
+ *   - a handle is thread-compatible (one caller at a time).
+ */
+#ifndef LCM_H_
+#define LCM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define LCM_API __attribute__((visibility("default")))
+#else
+#define LCM_API
+#endif
+
+#define LCM_DESC_BYTES 32          /* 256-bit ORB descriptor (README.md:115) */
+#define LCM_DESC_WORDS 8
+#define LCM_MAX_TRAIN_ROWS (1 << 22) /* packed (dist,idx) key: 9 + 22 bits */
+
+typedef enum lcm_status {
+    LCM_OK = 0,
+    LCM_ERR_INVALID_ARG = -1,
+    LCM_ERR_NO_DEVICE = -2,     /* no HIP device / runtime: the product path never falls back to CPU */
+    LCM_ERR_HIP = -3,           /* a HIP runtime call failed (message has hipGetErrorString) */
+    LCM_ERR_CAPACITY = -4,      /* output buffer or reserved database too small */
+    LCM_ERR_ORDER = -5,         /* frame ids must be appended in strictly increasing order */
+    LCM_ERR_NOT_FOUND = -6,     /* frame id not in this handle's database */
+    LCM_ERR_OOM = -7
+} lcm_status;
+
+/* Parameters the reference leaves to README prose (README.md:108-126).  Defaults (lcm_params_default):
+ * ratio=2, dist_floor=0, min_matches=50, sim_threshold=0.15, min_gap=30. */
+typedef struct lcm_params {
+    int32_t ratio;          /* good match: d <= max(ratio*min_d, dist_floor)      README.md:117 */
+    int32_t dist_floor;     /* README states no floor -> 0 */
+    int32_t min_matches;    /* loop needs good_count >= min_matches               README.md:124 */
+    int32_t min_gap;        /* compare only frames with cur_id - id >= min_gap    README.md:122, hpp:31 */
+    double  sim_threshold;  /* loop needs similarity > sim_threshold (strict)     README.md:123 */
+} lcm_params;
+
+/* One record per (query frame, stored frame) pair: what the device ships back (8 bytes).
+ * similarity = good_count / min(n_query, n_train) is formed on the host in IEEE double. */
+typedef struct lcm_score {
+    uint32_t good_count;    /* matches surviving the ratio*min_d filter */
+    uint16_t min_dist;      /* min over queries of the best distance; 0xFFFF if the pair is empty */
+    uint16_t n_train;       /* descriptor rows of the stored frame */
+} lcm_score;
+
+/* Same layout as cv::DMatch (int queryIdx, trainIdx, imgIdx; float distance) — 16 bytes. */
+typedef struct lcm_dmatch {
+    int32_t query_idx;
+    int32_t train_idx;
+    int32_t img_idx;        /* always 0: single train image */
+    float   distance;       /* integer-valued 0..256, exact in float */
+} lcm_dmatch;
+
+/* Same field order/types as loop_closing::LoopCandidate (include/loop_closing.hpp:22-27) — 24 bytes. */
+typedef struct lcm_loop_candidate {
+    int32_t current_frame_id;
+    int32_t matched_frame_id;
+    int32_t num_matches;
+    double  similarity_score;
+} lcm_loop_candidate;
+
+/* Timing of the most recent bulk launch on this handle, from hipEvents on the launch stream. */
+typedef struct lcm_launch_info {
+    double   kernel_ms;         /* device time of the pair-match kernel(s) of the last bulk call */
+    uint64_t pairs;             /* (query frame, stored frame) pairs scored */
+    uint64_t distances;         /* sum over pairs of n_query * n_train */
+    uint64_t algo_bytes;        /* sum n_train*32 per pair + n_query*32 per query frame + 8 per pair */
+    uint32_t launches;          /* kernel launches that made up the call */
+    uint32_t workgroups;        /* workgroups of the (largest) launch */
+} lcm_launch_info;
+
+typedef struct lcm_handle lcm_handle;
+
+LCM_API void        lcm_params_default(lcm_params* p);
+LCM_API const char* lcm_last_error(void);
+LCM_API const char* lcm_backend_name(void);         /* "hip-gfx950" */
+LCM_API int         lcm_device_count(void);         /* #HIP devices, 0 if none / no runtime */
+
+/* Create a matcher bound to HIP device `device_id`.  `stream` is a hipStream_t (as void*) that all work is
+ * enqueued on, or NULL for a library-owned stream. */
+LCM_API int  lcm_create(const lcm_params* params, int device_id, void* stream, lcm_handle** out);
+LCM_API void lcm_destroy(lcm_handle* h);
+LCM_API int  lcm_set_params(lcm_handle* h, const lcm_params* params);
+LCM_API int  lcm_get_params(const lcm_handle* h, lcm_params* params);
+LCM_API int  lcm_sync(lcm_handle* h);
+
+/* ---- stored-frame descriptor database (device resident) -------------------------------------------- */
+/* Reserve room for `n_frames` frames of up to `max_desc` rows each.  Growing later is allowed (copying). */
+LCM_API int  lcm_db_reserve(lcm_handle* h, int n_frames, int max_desc);
+/* Append one frame (host rows).  Copies through pinned staging with hipMemcpyAsync on a copy stream that
+ * overlaps matching; the caller may reuse `desc` as soon as the call returns.  `n_keypoints` is the
+ * similarity denominator (Frame::keypoints.size(), == n for ORB); pass -1 to use `n`. */
+LCM_API int  lcm_db_append(lcm_handle* h, int frame_id, const uint8_t* desc, int n, int n_keypoints);
+/* Same, rows already in device memory (n x 32 bytes, contiguous). */
+LCM_API int  lcm_db_append_device(lcm_handle* h, int frame_id, const void* d_desc, int n, int n_keypoints);
+LCM_API int  lcm_db_size(const lcm_handle* h);                 /* frames stored */
+LCM_API int  lcm_db_clear(lcm_handle* h);
+LCM_API int  lcm_db_frame_info(const lcm_handle* h, int slot, int* frame_id, int* n_desc, int* n_keypoints);
+/* Copy a stored frame's rows back to the host (tests / snapshot). */
+LCM_API int  lcm_db_read(lcm_handle* h, int slot, uint8_t* desc_out, int cap_rows);
+
+/* ---- pair mode: BFMatcher(NORM_HAMMING, crossCheck=false).match ------------------------------------ */
+/* For each query row q (ascending): train_idx[q] = FIRST index of the minimum Hamming distance over the
+ * nt train rows, dist[q] = that distance.  nq == 0 or nt == 0: nothing is written, *n_matches = 0. */
+LCM_API int  lcm_match_pair(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                            int32_t* train_idx, uint16_t* dist, int* n_matches);
+/* matchFeatures: the above + keep matches with d <= max(ratio*min_d, dist_floor), query order preserved.
+ * `out` needs room for nq records. */
+LCM_API int  lcm_match_features(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                                lcm_dmatch* out, int* n_out, int* min_dist);
+
+/* ---- loop search against the stored database --------------------------------------------------------- */
+/* Score `query` (id query_frame_id) against every stored frame with query_frame_id - id >= min_gap, ascending
+ * slot order.  out_scores / out_frame_ids need room for lcm_db_size() records. */
+LCM_API int  lcm_query_scores(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id,
+                              lcm_score* out_scores, int32_t* out_frame_ids, int* n_out);
+/* detectLoops for a frame that is already stored (or given explicitly with query != NULL). */
+LCM_API int  lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
+                              lcm_loop_candidate* out, int cap, int* n_out);
+/* Host-side loop test on shipped integers: similarity in IEEE double, strict '>' on the threshold
+ * (README.md:123-126).  Returns 1 if the pair is a loop candidate. */
+LCM_API int  lcm_loop_test(const lcm_params* p, const lcm_score* s, int n_query_kp, int n_train_kp,
+                           double* similarity);
+
+/* ---- bulk all-vs-all (benchmark / re-scan mode) ---------------------------------------------------- */
+/* Query set: `n_q_frames` frames at d_query_rows + i*q_stride_rows*32 (device memory), row counts
+ * d_query_counts[i] (device, int32), ids q_ids[i] (host, strictly increasing).  If d_query_rows is NULL the
+ * handle's own database is the query set.  Every query frame is scored against every stored frame of this
+ * handle with q_id - id >= min_gap.  Scores are written to the device buffer d_scores (lcm_score records) in
+ * (query ascending, stored slot ascending) order; *n_pairs receives the count; pair_offsets (host, optional,
+ * n_q_frames+1 entries) receives the start of each query frame's run.  d_scores may be NULL to size first. */
+LCM_API int  lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
+                            const int32_t* q_ids, int n_q_frames, int q_stride_rows,
+                            void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets);
+LCM_API int  lcm_last_launch_info(const lcm_handle* h, lcm_launch_info* info);
+
+/* Select the pair-match kernel variant: 0 = default, see DESIGN.md (for A/B measurement only). */
+LCM_API int  lcm_set_kernel_variant(lcm_handle* h, int variant);
+
+/* Device scratch helpers so a host program needs no other allocator (plain hipMalloc/hipFree/hipMemcpy). */
+LCM_API int  lcm_dev_alloc(lcm_handle* h, size_t bytes, void** d_ptr);
+LCM_API int  lcm_dev_free(lcm_handle* h, void* d_ptr);
+LCM_API int  lcm_dev_upload(lcm_handle* h, void* d_dst, const void* src, size_t bytes);
+LCM_API int  lcm_dev_download(lcm_handle* h, void* dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCM_H_ */

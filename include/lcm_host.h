@@ -1,0 +1,40 @@
+/*
+ * lcm_host.h — C shim over the C++ host class loop_closing::LoopClosingSystem
+ * (slam-loop-closing_amd/csrc/loop_closing_system.hpp), the host-side mirror of the reference's
+ * include/loop_closing.hpp:29-80 for the Hamming path.  It exists so that non-C++ callers (the ctypes parity
+ * tests) can drive the same object a C++ program would; C++ callers include loop_closing_system.hpp directly.
+ * Same conventions as lcm.h (int status, lcm_last_error()).
+ */
+#ifndef LCM_HOST_H_
+#define LCM_HOST_H_
+
+#include "lcm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lcs_system lcs_system;
+
+/* LoopClosingSystem(loop_threshold, min_loop_gap) — include/loop_closing.hpp:31 (defaults 0.7 / 30).
+ * shard_rank/shard_world: this process owns stored frames whose arrival position % shard_world == shard_rank
+ * (1-GPU: 0 / 1). */
+LCM_API int  lcs_create(double loop_threshold, int min_loop_gap, int device_id, int shard_rank, int shard_world,
+                        lcs_system** out);
+LCM_API void lcs_destroy(lcs_system* s);
+/* processFrame (include/loop_closing.hpp:34) with the ORB stage already done: `desc` is what
+ * detectFeatures would have put in Frame::descriptors (rows x 32, CV_8U), n_keypoints = keypoints.size(). */
+LCM_API int  lcs_process_frame(lcs_system* s, const uint8_t* desc, int rows, int n_keypoints, int frame_id);
+/* matchFeatures(frame1, frame2) for two stored frames given by id (include/loop_closing.hpp:40). */
+LCM_API int  lcs_match_features(lcs_system* s, int frame1_id, int frame2_id, lcm_dmatch* out, int cap, int* n_out);
+/* detectLoops(current_frame_id) (include/loop_closing.hpp:48). */
+LCM_API int  lcs_detect_loops(lcs_system* s, int current_frame_id, lcm_loop_candidate* out, int cap, int* n_out);
+LCM_API int  lcs_num_frames(const lcs_system* s);                       /* getFrames().size()        hpp:60 */
+LCM_API int  lcs_num_loop_closures(const lcs_system* s);                /* getLoopClosures().size()  hpp:63 */
+LCM_API int  lcs_get_loop_closures(const lcs_system* s, lcm_loop_candidate* out, int cap, int* n_out);
+LCM_API int  lcs_save_results(lcs_system* s, const char* output_dir);   /* saveResults               hpp:66 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

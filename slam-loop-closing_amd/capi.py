@@ -1,0 +1,310 @@
+"""ctypes binding of include/lcm.h — the C ABI of the MI355X loop-closure matcher.
+
+This module is plumbing for tests, bench.py and __graft_entry__: the product is the shared library
+`lib/liblcm_hip.so` (hand-written gfx950 kernels behind a C ABI).  There is no Python or CPU compute path here;
+if the library is missing or no HIP device is present, everything raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblcm_hip.so")
+DESC_BYTES = 32
+KEY_SHIFT = 22
+
+
+class LcmError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"lcm error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("ratio", C.c_int32), ("dist_floor", C.c_int32), ("min_matches", C.c_int32),
+                ("min_gap", C.c_int32), ("sim_threshold", C.c_double)]
+
+
+class Score(C.Structure):
+    _fields_ = [("good_count", C.c_uint32), ("min_dist", C.c_uint16), ("n_train", C.c_uint16)]
+
+
+class DMatch(C.Structure):
+    _fields_ = [("query_idx", C.c_int32), ("train_idx", C.c_int32), ("img_idx", C.c_int32), ("distance", C.c_float)]
+
+
+class LoopCandidate(C.Structure):
+    _fields_ = [("current_frame_id", C.c_int32), ("matched_frame_id", C.c_int32), ("num_matches", C.c_int32),
+                ("similarity_score", C.c_double)]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("pairs", C.c_uint64), ("distances", C.c_uint64),
+                ("algo_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32)]
+
+
+SCORE_DTYPE = np.dtype([("good_count", "<u4"), ("min_dist", "<u2"), ("n_train", "<u2")])
+DMATCH_DTYPE = np.dtype([("query_idx", "<i4"), ("train_idx", "<i4"), ("img_idx", "<i4"), ("distance", "<f4")])
+CANDIDATE_DTYPE = np.dtype([("current_frame_id", "<i4"), ("matched_frame_id", "<i4"), ("num_matches", "<i4"),
+                            ("_pad", "<i4"), ("similarity_score", "<f8")])
+assert SCORE_DTYPE.itemsize == C.sizeof(Score) == 8
+assert DMATCH_DTYPE.itemsize == C.sizeof(DMatch) == 16
+assert CANDIDATE_DTYPE.itemsize == C.sizeof(LoopCandidate) == 24
+
+_lib = None
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/lcm.h one to one (tests/test_abi.py checks the symbol list)
+_SIGNATURES = {
+    "lcm_params_default": (None, [C.POINTER(Params)]),
+    "lcm_last_error": (C.c_char_p, []),
+    "lcm_backend_name": (C.c_char_p, []),
+    "lcm_device_count": (C.c_int, []),
+    "lcm_create": (C.c_int, [C.POINTER(Params), C.c_int, _vp, C.POINTER(_vp)]),
+    "lcm_destroy": (None, [_vp]),
+    "lcm_set_params": (C.c_int, [_vp, C.POINTER(Params)]),
+    "lcm_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
+    "lcm_sync": (C.c_int, [_vp]),
+    "lcm_db_reserve": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "lcm_db_append": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
+    "lcm_db_append_device": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
+    "lcm_db_size": (C.c_int, [_vp]),
+    "lcm_db_clear": (C.c_int, [_vp]),
+    "lcm_db_frame_info": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
+    "lcm_db_read": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    "lcm_match_pair": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _i32p]),
+    "lcm_match_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _i32p, _i32p]),
+    "lcm_query_scores": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _i32p]),
+    "lcm_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
+    "lcm_loop_test": (C.c_int, [C.POINTER(Params), C.POINTER(Score), C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "lcm_all_vs_all": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
+                                  C.POINTER(C.c_size_t), _vp]),
+    "lcm_last_launch_info": (C.c_int, [_vp, C.POINTER(LaunchInfo)]),
+    "lcm_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
+    "lcm_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "lcm_dev_free": (C.c_int, [_vp, _vp]),
+    "lcm_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "lcm_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+}
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the C-ABI library.  Raises OSError if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback)")
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise LcmError(rc, load_library().lcm_last_error().decode("utf-8", "replace"))
+
+
+def default_params() -> Params:
+    p = Params()
+    load_library().lcm_params_default(C.byref(p))
+    return p
+
+
+def _rows(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2 or a.shape[1] != DESC_BYTES:
+        raise ValueError(f"descriptor matrix must be (n, {DESC_BYTES}) uint8, got {a.shape}")
+    return a
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None or a.size == 0 else a.ctypes.data_as(_vp)
+
+
+class Matcher:
+    """One matcher handle bound to one HIP device (one process per GPU)."""
+
+    def __init__(self, params: Optional[Params] = None, device: int = 0, stream: Optional[int] = None):
+        self._lib = load_library()
+        self._h = _vp()
+        p = params if params is not None else default_params()
+        _check(self._lib.lcm_create(C.byref(p), device, _vp(stream) if stream else None, C.byref(self._h)))
+
+    # -- lifetime ----------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lcm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- parameters --------------------------------------------------------------------------------
+    @property
+    def params(self) -> Params:
+        p = Params()
+        _check(self._lib.lcm_get_params(self._h, C.byref(p)))
+        return p
+
+    def set_params(self, **kw):
+        p = self.params
+        for k, v in kw.items():
+            setattr(p, k, v)
+        _check(self._lib.lcm_set_params(self._h, C.byref(p)))
+
+    def set_kernel_variant(self, v: int):
+        _check(self._lib.lcm_set_kernel_variant(self._h, v))
+
+    def sync(self):
+        _check(self._lib.lcm_sync(self._h))
+
+    # -- database ----------------------------------------------------------------------------------
+    def reserve(self, n_frames: int, max_desc: int):
+        _check(self._lib.lcm_db_reserve(self._h, n_frames, max_desc))
+
+    def append(self, frame_id: int, desc, n_keypoints: int = -1):
+        d = _rows(desc)
+        _check(self._lib.lcm_db_append(self._h, frame_id, _ptr(d), d.shape[0], n_keypoints))
+
+    def append_device(self, frame_id: int, d_ptr: int, n: int, n_keypoints: int = -1):
+        _check(self._lib.lcm_db_append_device(self._h, frame_id, _vp(d_ptr), n, n_keypoints))
+
+    def __len__(self):
+        return self._lib.lcm_db_size(self._h)
+
+    def clear(self):
+        _check(self._lib.lcm_db_clear(self._h))
+
+    def frame_info(self, slot: int) -> Tuple[int, int, int]:
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(self._lib.lcm_db_frame_info(self._h, slot, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def read_frame(self, slot: int) -> np.ndarray:
+        _, n, _ = self.frame_info(slot)
+        out = np.empty((n, DESC_BYTES), np.uint8)
+        _check(self._lib.lcm_db_read(self._h, slot, _ptr(out) if n else None, n))
+        return out
+
+    # -- pair mode ---------------------------------------------------------------------------------
+    def match_pair(self, query, train) -> Tuple[np.ndarray, np.ndarray]:
+        """BFMatcher(NORM_HAMMING).match: (train_idx int32[n], dist uint16[n]); n = 0 if either side is empty."""
+        q, t = _rows(query), _rows(train)
+        idx = np.empty(q.shape[0], np.int32)
+        dist = np.empty(q.shape[0], np.uint16)
+        n = C.c_int32(0)
+        _check(self._lib.lcm_match_pair(self._h, _ptr(q), q.shape[0], _ptr(t), t.shape[0], _ptr(idx), _ptr(dist),
+                                        C.byref(n)))
+        return idx[: n.value], dist[: n.value]
+
+    def match_features(self, query, train) -> Tuple[np.ndarray, int]:
+        """matchFeatures: structured array of DMatch records that survive the ratio*min filter, and min_dist."""
+        q, t = _rows(query), _rows(train)
+        out = np.zeros(max(q.shape[0], 1), DMATCH_DTYPE)
+        n, m = C.c_int32(0), C.c_int32(0)
+        _check(self._lib.lcm_match_features(self._h, _ptr(q), q.shape[0], _ptr(t), t.shape[0],
+                                            out.ctypes.data_as(_vp), C.byref(n), C.byref(m)))
+        return out[: n.value], m.value
+
+    # -- loop search -------------------------------------------------------------------------------
+    def query_scores(self, query, query_frame_id: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _rows(query)
+        cap = max(len(self), 1)
+        scores = np.zeros(cap, SCORE_DTYPE)
+        ids = np.zeros(cap, np.int32)
+        n = C.c_int32(0)
+        _check(self._lib.lcm_query_scores(self._h, _ptr(q), q.shape[0], query_frame_id, scores.ctypes.data_as(_vp),
+                                          ids.ctypes.data_as(_vp), C.byref(n)))
+        return scores[: n.value], ids[: n.value]
+
+    def detect_loops(self, current_frame_id: int, query=None, n_keypoints: int = -1) -> np.ndarray:
+        cap = max(len(self), 1)
+        out = np.zeros(cap, CANDIDATE_DTYPE)
+        n = C.c_int32(0)
+        if query is None:
+            qp, nq = None, 0
+        else:
+            q = _rows(query)
+            nq = q.shape[0]
+            # an explicit empty frame still needs a non-NULL pointer to be told apart from "use the stored frame"
+            qp = q.ctypes.data_as(_vp) if nq else np.zeros((1, DESC_BYTES), np.uint8).ctypes.data_as(_vp)
+        _check(self._lib.lcm_detect_loops(self._h, current_frame_id, qp, nq, n_keypoints, out.ctypes.data_as(_vp), cap,
+                                          C.byref(n)))
+        return out[: n.value]
+
+    def loop_test(self, score, n_query_kp: int, n_train_kp: int) -> Tuple[bool, float]:
+        s = Score(int(score["good_count"]), int(score["min_dist"]), int(score["n_train"]))
+        p = self.params
+        sim = C.c_double(0)
+        r = self._lib.lcm_loop_test(C.byref(p), C.byref(s), n_query_kp, n_train_kp, C.byref(sim))
+        return bool(r), sim.value
+
+    # -- bulk --------------------------------------------------------------------------------------
+    def all_vs_all_plan(self, d_query_rows: int = 0, d_query_counts: int = 0, q_ids: Optional[Sequence[int]] = None,
+                        q_stride_rows: int = 0) -> Tuple[int, np.ndarray]:
+        """Sizing call: returns (n_pairs, offsets[n_q_frames + 1])."""
+        ids = None if q_ids is None else np.ascontiguousarray(q_ids, np.int32)
+        nq = len(self) if ids is None else ids.shape[0]
+        offs = np.zeros(nq + 1, np.uintp)
+        n = C.c_size_t(0)
+        _check(self._lib.lcm_all_vs_all(self._h, _vp(d_query_rows) if d_query_rows else None,
+                                        _vp(d_query_counts) if d_query_counts else None, _ptr(ids), nq, q_stride_rows,
+                                        None, 0, C.byref(n), offs.ctypes.data_as(_vp)))
+        return n.value, offs
+
+    def all_vs_all(self, d_scores: int, scores_cap: int, d_query_rows: int = 0, d_query_counts: int = 0,
+                   q_ids: Optional[Sequence[int]] = None, q_stride_rows: int = 0) -> int:
+        """Enqueue the bulk scoring on the handle's stream; scores land in device memory at d_scores."""
+        ids = None if q_ids is None else np.ascontiguousarray(q_ids, np.int32)
+        nq = len(self) if ids is None else ids.shape[0]
+        n = C.c_size_t(0)
+        _check(self._lib.lcm_all_vs_all(self._h, _vp(d_query_rows) if d_query_rows else None,
+                                        _vp(d_query_counts) if d_query_counts else None, _ptr(ids), nq, q_stride_rows,
+                                        _vp(d_scores), scores_cap, C.byref(n), None))
+        return n.value
+
+    def launch_info(self) -> LaunchInfo:
+        info = LaunchInfo()
+        _check(self._lib.lcm_last_launch_info(self._h, C.byref(info)))
+        return info
+
+    # -- device scratch ----------------------------------------------------------------------------
+    def dev_alloc(self, nbytes: int) -> int:
+        p = _vp()
+        _check(self._lib.lcm_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, d_ptr: int):
+        _check(self._lib.lcm_dev_free(self._h, _vp(d_ptr)))
+
+    def dev_upload(self, d_ptr: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        _check(self._lib.lcm_dev_upload(self._h, _vp(d_ptr), a.ctypes.data_as(_vp), a.nbytes))
+
+    def dev_download(self, d_ptr: int, out: np.ndarray):
+        assert out.flags["C_CONTIGUOUS"]
+        _check(self._lib.lcm_dev_download(self._h, out.ctypes.data_as(_vp), _vp(d_ptr), out.nbytes))

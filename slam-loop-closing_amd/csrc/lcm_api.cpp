@@ -1,0 +1,780 @@
+// lcm_api.cpp — host side of the C ABI declared in include/lcm.h (compiled with hipcc, gfx950 only).
+//
+// Owns: the device-resident stored-frame descriptor database (the `frames_` vector of
+// loop_closing::LoopClosingSystem, include/loop_closing.hpp:69, reduced to what the Hamming path reads:
+// id, row count, keypoint count, 32-byte rows), pinned staging for streaming appends, work-list planning for the
+// pair-scoring kernel, and the host-side IEEE-double loop test (README.md:123-126).
+//
+// There is no CPU compute path in this file: every distance is computed by the kernels in lcm_kernels.hip.
+#include "../../include/lcm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lcm_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? LCM_ERR_OOM : LCM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                \
+    } while (0)
+
+constexpr int ROW_PAD = 4;            // stored rows are padded to a multiple of 4 with copies of the last row
+constexpr size_t ARENA_SLACK = 512;   // the kernel prefetches up to 4 rows past a frame's padded end
+constexpr int DEFAULT_MAX_DESC = 2000;  // ORB nfeatures of the reference (README.md:114)
+constexpr int STAGE_BUFS = 2;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct FrameMeta {
+    int32_t id;
+    int32_t n;       // descriptor rows
+    int32_t n_kp;    // keypoints (similarity denominator)
+};
+
+struct Plan {            // cached work list of one bulk call shape
+    uint64_t key = 0;    // hash of what it was built from
+    std::vector<lcm::WorkItem> items;
+    std::vector<size_t> offsets;    // per query frame, start of its run of pairs (n_q + 1)
+    lcm::WorkItem* d_items = nullptr;
+    size_t d_items_cap = 0;
+    size_t n_pairs = 0;
+    uint64_t distances = 0, algo_bytes = 0;
+    int max_q_rows = 0;
+};
+
+}  // namespace
+
+struct lcm_handle {
+    lcm_params params;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t db_ready = nullptr;     // last append landed (recorded on copy_stream)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int variant = 0;
+
+    // database arena
+    uint8_t* d_rows = nullptr;
+    int32_t* d_counts = nullptr;
+    int cap_frames = 0;
+    int stride_rows = 0;               // rows per frame slot (multiple of ROW_PAD)
+    std::vector<FrameMeta> frames;
+    bool pending_copy = false;
+
+    // pinned staging ring for streaming appends
+    uint8_t* h_stage[STAGE_BUFS] = {nullptr, nullptr};
+    size_t h_stage_bytes = 0;
+    hipEvent_t stage_done[STAGE_BUFS] = {nullptr, nullptr};
+    int32_t* h_counts = nullptr;       // pinned mirror of d_counts (source of the 4-byte async copies)
+    int h_counts_cap = 0;
+    int stage_next = 0;
+
+    // scratch for query uploads / pair mode / results
+    uint8_t* d_qbuf = nullptr;  size_t d_qbuf_bytes = 0;
+    int32_t* d_qcounts = nullptr; size_t d_qcounts_n = 0;
+    uint8_t* d_tbuf = nullptr;  size_t d_tbuf_bytes = 0;
+    int32_t* d_tcounts = nullptr;
+    uint32_t* d_keys = nullptr; size_t d_keys_n = 0;
+    lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
+    lcm::WorkItem* d_items = nullptr; size_t d_items_n = 0;
+    std::vector<lcm_score> h_scores;
+
+    Plan plan;
+    lcm_launch_info info{};
+    bool info_pending = false;
+};
+
+namespace {
+
+int set_device(const lcm_handle* h) {
+    HIP_TRY(hipSetDevice(h->device));
+    return LCM_OK;
+}
+
+template <typename T>
+int ensure_dev(T*& p, size_t& have, size_t need, size_t slack_bytes = 0) {
+    if (need <= have && p) return LCM_OK;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr; have = 0;
+    size_t n = std::max<size_t>(need, 16);
+    HIP_TRY(hipMalloc((void**)&p, n * sizeof(T) + slack_bytes));
+    have = n;
+    return LCM_OK;
+}
+
+int wait_db(lcm_handle* h) {   // make the match stream see every append issued so far
+    if (h->pending_copy) {
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->db_ready, 0));
+        h->pending_copy = false;
+    }
+    return LCM_OK;
+}
+
+int grow_arena(lcm_handle* h, int need_frames, int need_rows) {
+    int new_stride = std::max(h->stride_rows, round_up(std::max(need_rows, 1), ROW_PAD));
+    int new_cap = h->cap_frames;
+    if (need_frames > new_cap) new_cap = std::max(need_frames, std::max(64, h->cap_frames * 2));
+    if (new_stride == h->stride_rows && new_cap == h->cap_frames && h->d_rows) return LCM_OK;
+    if (new_stride > 65535) return fail(LCM_ERR_CAPACITY, "a stored frame may hold at most 65535 rows (got %d)", need_rows);
+
+    uint8_t* nrows = nullptr;
+    int32_t* ncounts = nullptr;
+    size_t bytes = (size_t)new_cap * new_stride * LCM_DESC_BYTES + ARENA_SLACK;
+    HIP_TRY(hipMalloc((void**)&nrows, bytes));
+    HIP_TRY(hipMalloc((void**)&ncounts, sizeof(int32_t) * (size_t)new_cap));
+    HIP_TRY(hipMemsetAsync(nrows, 0, bytes, h->stream));
+    HIP_TRY(hipMemsetAsync(ncounts, 0, sizeof(int32_t) * (size_t)new_cap, h->stream));
+    int n = (int)h->frames.size();
+    if (n > 0 && h->d_rows) {
+        // all appends must have landed before the old arena is re-pitched
+        HIP_TRY(hipStreamSynchronize(h->copy_stream));
+        HIP_TRY(hipMemcpy2DAsync(nrows, (size_t)new_stride * LCM_DESC_BYTES, h->d_rows,
+                                 (size_t)h->stride_rows * LCM_DESC_BYTES, (size_t)h->stride_rows * LCM_DESC_BYTES,
+                                 (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(ncounts, h->d_counts, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_rows) HIP_TRY(hipFree(h->d_rows));
+    if (h->d_counts) HIP_TRY(hipFree(h->d_counts));
+    h->d_rows = nrows; h->d_counts = ncounts;
+    h->cap_frames = new_cap; h->stride_rows = new_stride;
+    h->plan.key = 0;
+
+    if (new_cap > h->h_counts_cap) {
+        int32_t* nc = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&nc, sizeof(int32_t) * (size_t)new_cap, hipHostMallocDefault));
+        if (h->h_counts) { memcpy(nc, h->h_counts, sizeof(int32_t) * (size_t)h->h_counts_cap); HIP_TRY(hipHostFree(h->h_counts)); }
+        h->h_counts = nc; h->h_counts_cap = new_cap;
+    }
+    size_t stage_need = (size_t)new_stride * LCM_DESC_BYTES;
+    if (stage_need > h->h_stage_bytes) {
+        for (int i = 0; i < STAGE_BUFS; ++i) {
+            if (h->h_stage[i]) { HIP_TRY(hipEventSynchronize(h->stage_done[i])); HIP_TRY(hipHostFree(h->h_stage[i])); }
+            HIP_TRY(hipHostMalloc((void**)&h->h_stage[i], stage_need, hipHostMallocDefault));
+        }
+        h->h_stage_bytes = stage_need;
+    }
+    return LCM_OK;
+}
+
+int check_append(lcm_handle* h, int frame_id, int n) {
+    if (n < 0) return fail(LCM_ERR_INVALID_ARG, "negative row count %d", n);
+    if (!h->frames.empty() && frame_id <= h->frames.back().id)
+        return fail(LCM_ERR_ORDER, "frame id %d appended after id %d: ids must be strictly increasing", frame_id,
+                    h->frames.back().id);
+    int need_frames = (int)h->frames.size() + 1;
+    if (need_frames > h->cap_frames || n > h->stride_rows || !h->d_rows) {
+        int want_rows = std::max(n, h->stride_rows > 0 ? h->stride_rows : DEFAULT_MAX_DESC);
+        int rc = grow_arena(h, need_frames, want_rows);
+        if (rc) return rc;
+    }
+    return LCM_OK;
+}
+
+// rows [n, round_up(n,4)) of a stored frame are copies of row n-1 (see lcm_kernels.hip)
+inline int padded_rows(int n) { return round_up(n, ROW_PAD); }
+
+uint64_t mix(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    return h;
+}
+
+// Eligible stored slots for a query id are a prefix because ids are strictly increasing by slot.
+int eligible_prefix(const lcm_handle* h, int query_id, int gap) {
+    // largest e with frames[e-1].id <= query_id - gap; a frame is never compared with itself (gap >= 1)
+    long long lim = (long long)query_id - std::max(gap, 1);
+    int lo = 0, hi = (int)h->frames.size();
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if ((long long)h->frames[mid].id <= lim) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+int pick_chunk(size_t total_pairs) {
+    // enough work items to fill 256 CUs several times over, few enough to amortise the query-frame load
+    if (total_pairs >= 65536) return 8;
+    if (total_pairs >= 16384) return 4;
+    if (total_pairs >= 4096) return 2;
+    return 1;
+}
+
+int launch_and_time(lcm_handle* h, const lcm::ScoreArgs& a, uint32_t n_items, int max_q_rows, bool write_keys) {
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    hipError_t e = lcm::launch_score(a, n_items, max_q_rows, write_keys, h->variant, h->stream);
+    if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    h->info_pending = true;
+    h->info.launches = 1;
+    h->info.workgroups = n_items;
+    return LCM_OK;
+}
+
+// Upload host rows into a scratch device buffer as `n_chunks` pseudo-frames of `chunk_rows` rows.
+int upload_rows(lcm_handle* h, uint8_t*& d_buf, size_t& d_bytes, const uint8_t* rows, int n, int stride_rows_total,
+                bool pad_last) {
+    size_t need = (size_t)stride_rows_total * LCM_DESC_BYTES;
+    {
+        size_t have = d_bytes;
+        uint8_t* p = d_buf;
+        int rc = ensure_dev(p, have, need, ARENA_SLACK);
+        d_buf = p; d_bytes = have;
+        if (rc) return rc;
+    }
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(d_buf, rows, (size_t)n * LCM_DESC_BYTES, hipMemcpyHostToDevice, h->stream));
+        if (pad_last) {
+            for (int r = n; r < padded_rows(n); ++r)
+                HIP_TRY(hipMemcpyAsync(d_buf + (size_t)r * LCM_DESC_BYTES, rows + (size_t)(n - 1) * LCM_DESC_BYTES,
+                                       LCM_DESC_BYTES, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    return LCM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void lcm_params_default(lcm_params* p) {
+    if (!p) return;
+    p->ratio = 2;
+    p->dist_floor = 0;
+    p->min_matches = 50;
+    p->min_gap = 30;
+    p->sim_threshold = 0.15;
+}
+
+const char* lcm_last_error(void) { return g_err.c_str(); }
+const char* lcm_backend_name(void) { return "hip-gfx950"; }
+
+int lcm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int lcm_create(const lcm_params* params, int device_id, void* stream, lcm_handle** out) {
+    if (!out) return fail(LCM_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(LCM_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    if (device_id < 0 || device_id >= ndev) return fail(LCM_ERR_INVALID_ARG, "device_id %d out of range [0,%d)", device_id, ndev);
+    lcm_handle* h = new (std::nothrow) lcm_handle();
+    if (!h) return fail(LCM_ERR_OOM, "host allocation failed");
+    if (params) h->params = *params; else lcm_params_default(&h->params);
+    h->device = device_id;
+    auto bail = [&](int rc) { lcm_destroy(h); return rc; };
+    if (hipSetDevice(device_id) != hipSuccess) return bail(fail(LCM_ERR_HIP, "hipSetDevice(%d) failed", device_id));
+    if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(LCM_ERR_HIP, "hipStreamCreate failed"));
+        h->own_stream = true;
+    }
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(LCM_ERR_HIP, "hipStreamCreate(copy) failed"));
+    if (hipEventCreateWithFlags(&h->db_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess)
+        return bail(fail(LCM_ERR_HIP, "hipEventCreate failed"));
+    for (int i = 0; i < STAGE_BUFS; ++i) {
+        if (hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming) != hipSuccess)
+            return bail(fail(LCM_ERR_HIP, "hipEventCreate failed"));
+    }
+    *out = h;
+    return LCM_OK;
+}
+
+void lcm_destroy(lcm_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    (void)hipFree(h->d_rows); (void)hipFree(h->d_counts);
+    (void)hipFree(h->d_qbuf); (void)hipFree(h->d_qcounts); (void)hipFree(h->d_tbuf); (void)hipFree(h->d_tcounts);
+    (void)hipFree(h->d_keys); (void)hipFree(h->d_scores); (void)hipFree(h->d_items); (void)hipFree(h->plan.d_items);
+    for (int i = 0; i < STAGE_BUFS; ++i) {
+        if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+        if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
+    }
+    if (h->h_counts) (void)hipHostFree(h->h_counts);
+    if (h->db_ready) (void)hipEventDestroy(h->db_ready);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int lcm_set_params(lcm_handle* h, const lcm_params* p) {
+    if (!h || !p) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    if (p->ratio < 0 || p->dist_floor < 0 || p->min_gap < 0) return fail(LCM_ERR_INVALID_ARG, "negative parameter");
+    h->params = *p;
+    h->plan.key = 0;
+    return LCM_OK;
+}
+
+int lcm_get_params(const lcm_handle* h, lcm_params* p) {
+    if (!h || !p) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    *p = h->params;
+    return LCM_OK;
+}
+
+int lcm_sync(lcm_handle* h) {
+    if (!h) return fail(LCM_ERR_INVALID_ARG, "NULL handle");
+    int rc = set_device(h); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->copy_stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return LCM_OK;
+}
+
+int lcm_set_kernel_variant(lcm_handle* h, int variant) {
+    if (!h) return fail(LCM_ERR_INVALID_ARG, "NULL handle");
+    if (variant < 0 || variant > 1) return fail(LCM_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
+    h->variant = variant;
+    return LCM_OK;
+}
+
+/* ---- database ---------------------------------------------------------------------------------------- */
+
+int lcm_db_reserve(lcm_handle* h, int n_frames, int max_desc) {
+    if (!h || n_frames < 0 || max_desc < 0) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    int rc = set_device(h); if (rc) return rc;
+    return grow_arena(h, std::max(n_frames, 1), std::max(max_desc, 1));
+}
+
+int lcm_db_append(lcm_handle* h, int frame_id, const uint8_t* desc, int n, int n_keypoints) {
+    if (!h || (n > 0 && !desc)) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    int rc = set_device(h); if (rc) return rc;
+    rc = check_append(h, frame_id, n); if (rc) return rc;
+    const int slot = (int)h->frames.size();
+    const int b = h->stage_next;
+    h->stage_next = (b + 1) % STAGE_BUFS;
+    // the staging buffer is free once the copy that last used it has completed
+    HIP_TRY(hipEventSynchronize(h->stage_done[b]));
+    const int np = padded_rows(n);
+    if (n > 0) {
+        memcpy(h->h_stage[b], desc, (size_t)n * LCM_DESC_BYTES);
+        for (int r = n; r < np; ++r) memcpy(h->h_stage[b] + (size_t)r * LCM_DESC_BYTES, desc + (size_t)(n - 1) * LCM_DESC_BYTES, LCM_DESC_BYTES);
+        HIP_TRY(hipMemcpyAsync(h->d_rows + (size_t)slot * h->stride_rows * LCM_DESC_BYTES, h->h_stage[b],
+                               (size_t)np * LCM_DESC_BYTES, hipMemcpyHostToDevice, h->copy_stream));
+    }
+    h->h_counts[slot] = n;
+    HIP_TRY(hipMemcpyAsync(h->d_counts + slot, h->h_counts + slot, sizeof(int32_t), hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(hipEventRecord(h->stage_done[b], h->copy_stream));
+    HIP_TRY(hipEventRecord(h->db_ready, h->copy_stream));
+    h->pending_copy = true;
+    h->frames.push_back({frame_id, n, n_keypoints < 0 ? n : n_keypoints});
+    h->plan.key = 0;
+    return LCM_OK;
+}
+
+int lcm_db_append_device(lcm_handle* h, int frame_id, const void* d_desc, int n, int n_keypoints) {
+    if (!h || (n > 0 && !d_desc)) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    int rc = set_device(h); if (rc) return rc;
+    rc = check_append(h, frame_id, n); if (rc) return rc;
+    const int slot = (int)h->frames.size();
+    uint8_t* dst = h->d_rows + (size_t)slot * h->stride_rows * LCM_DESC_BYTES;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(dst, d_desc, (size_t)n * LCM_DESC_BYTES, hipMemcpyDeviceToDevice, h->stream));
+        for (int r = n; r < padded_rows(n); ++r)
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)r * LCM_DESC_BYTES, (const uint8_t*)d_desc + (size_t)(n - 1) * LCM_DESC_BYTES,
+                                   LCM_DESC_BYTES, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->h_counts[slot] = n;
+    HIP_TRY(hipMemcpyAsync(h->d_counts + slot, h->h_counts + slot, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    h->frames.push_back({frame_id, n, n_keypoints < 0 ? n : n_keypoints});
+    h->plan.key = 0;
+    return LCM_OK;
+}
+
+int lcm_db_size(const lcm_handle* h) { return h ? (int)h->frames.size() : 0; }
+
+int lcm_db_clear(lcm_handle* h) {
+    if (!h) return fail(LCM_ERR_INVALID_ARG, "NULL handle");
+    int rc = lcm_sync(h); if (rc) return rc;
+    h->frames.clear();
+    h->plan.key = 0;
+    return LCM_OK;
+}
+
+int lcm_db_frame_info(const lcm_handle* h, int slot, int* frame_id, int* n_desc, int* n_keypoints) {
+    if (!h || slot < 0 || slot >= (int)h->frames.size()) return fail(LCM_ERR_INVALID_ARG, "slot %d out of range", slot);
+    if (frame_id) *frame_id = h->frames[slot].id;
+    if (n_desc) *n_desc = h->frames[slot].n;
+    if (n_keypoints) *n_keypoints = h->frames[slot].n_kp;
+    return LCM_OK;
+}
+
+int lcm_db_read(lcm_handle* h, int slot, uint8_t* desc_out, int cap_rows) {
+    if (!h || slot < 0 || slot >= (int)h->frames.size()) return fail(LCM_ERR_INVALID_ARG, "slot out of range");
+    int n = h->frames[slot].n;
+    if (cap_rows < n) return fail(LCM_ERR_CAPACITY, "need room for %d rows", n);
+    int rc = lcm_sync(h); if (rc) return rc;
+    if (n > 0) HIP_TRY(hipMemcpy(desc_out, h->d_rows + (size_t)slot * h->stride_rows * LCM_DESC_BYTES, (size_t)n * LCM_DESC_BYTES, hipMemcpyDeviceToHost));
+    return LCM_OK;
+}
+
+/* ---- pair mode --------------------------------------------------------------------------------------- */
+
+// Computes the best packed key of every query row against all train rows; h->d_keys holds them afterwards
+// (chunk c of up to 2048 rows at keys[c*2048 ...]).  Returns the keys on the host in `keys_out`.
+static int pair_keys(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt, std::vector<uint32_t>& keys_out) {
+    int rc = set_device(h); if (rc) return rc;
+    if (nt > LCM_MAX_TRAIN_ROWS) return fail(LCM_ERR_CAPACITY, "at most %d train rows per call", LCM_MAX_TRAIN_ROWS);
+    const int CH = lcm::MAX_FUSED_QUERY_ROWS;
+    const int n_chunks = (nq + CH - 1) / CH;
+    // query rows as n_chunks pseudo-frames of CH rows
+    rc = upload_rows(h, h->d_qbuf, h->d_qbuf_bytes, query, nq, n_chunks * CH, false); if (rc) return rc;
+    rc = upload_rows(h, h->d_tbuf, h->d_tbuf_bytes, train, nt, padded_rows(nt) + ROW_PAD, true); if (rc) return rc;
+    std::vector<int32_t> qc(n_chunks);
+    std::vector<lcm::WorkItem> items(n_chunks);
+    for (int c = 0; c < n_chunks; ++c) {
+        qc[c] = std::min(CH, nq - c * CH);
+        items[c] = {(uint32_t)c, 0u, 1u, (uint32_t)c};
+    }
+    rc = ensure_dev(h->d_qcounts, h->d_qcounts_n, (size_t)n_chunks); if (rc) return rc;
+    if (!h->d_tcounts) HIP_TRY(hipMalloc((void**)&h->d_tcounts, 64));
+    rc = ensure_dev(h->d_items, h->d_items_n, (size_t)n_chunks); if (rc) return rc;
+    rc = ensure_dev(h->d_keys, h->d_keys_n, (size_t)n_chunks * CH); if (rc) return rc;
+    rc = ensure_dev(h->d_scores, h->d_scores_n, (size_t)n_chunks); if (rc) return rc;
+    int32_t ntc = nt;
+    HIP_TRY(hipMemcpyAsync(h->d_qcounts, qc.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_tcounts, &ntc, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_items, items.data(), sizeof(lcm::WorkItem) * n_chunks, hipMemcpyHostToDevice, h->stream));
+    lcm::ScoreArgs a{};
+    a.q_rows = (const uint32_t*)h->d_qbuf; a.q_counts = h->d_qcounts; a.q_stride_words = CH * LCM_DESC_WORDS;
+    a.db_rows = (const uint32_t*)h->d_tbuf; a.db_counts = h->d_tcounts; a.db_stride_words = 0;
+    a.items = h->d_items; a.scores = h->d_scores; a.keys = h->d_keys; a.keys_stride = CH;
+    a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
+    int max_rows = n_chunks > 1 ? CH : nq;
+    rc = launch_and_time(h, a, (uint32_t)n_chunks, max_rows, true); if (rc) return rc;
+    h->info.pairs = 1; h->info.distances = (uint64_t)nq * nt;
+    h->info.algo_bytes = (uint64_t)nt * 32 + (uint64_t)nq * 32 + 8;
+    keys_out.resize((size_t)n_chunks * CH);
+    HIP_TRY(hipMemcpyAsync(keys_out.data(), h->d_keys, sizeof(uint32_t) * keys_out.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return LCM_OK;
+}
+
+int lcm_match_pair(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                   int32_t* train_idx, uint16_t* dist, int* n_matches) {
+    if (!h || nq < 0 || nt < 0) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    if (n_matches) *n_matches = 0;
+    if (nq == 0 || nt == 0) return LCM_OK;            // BFMatcher: no train rows => no matches
+    if (!query || !train || !train_idx || !dist) return fail(LCM_ERR_INVALID_ARG, "NULL buffer");
+    std::vector<uint32_t> keys;
+    int rc = pair_keys(h, query, nq, train, nt, keys); if (rc) return rc;
+    for (int i = 0; i < nq; ++i) {
+        train_idx[i] = (int32_t)(keys[i] & lcm::KEY_IDX_MASK);
+        dist[i] = (uint16_t)(keys[i] >> lcm::KEY_SHIFT);
+    }
+    if (n_matches) *n_matches = nq;
+    return LCM_OK;
+}
+
+int lcm_match_features(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                       lcm_dmatch* out, int* n_out, int* min_dist) {
+    if (!h || nq < 0 || nt < 0 || !n_out) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    *n_out = 0;
+    if (min_dist) *min_dist = -1;
+    if (nq == 0 || nt == 0) return LCM_OK;
+    if (!query || !train || !out) return fail(LCM_ERR_INVALID_ARG, "NULL buffer");
+    std::vector<uint32_t> keys;
+    int rc = pair_keys(h, query, nq, train, nt, keys); if (rc) return rc;
+    // README.md:117 filter on the shipped integers (O(nq) bookkeeping, no distance is computed here)
+    uint32_t m = 0xFFFFFFFFu;
+    for (int i = 0; i < nq; ++i) m = std::min(m, keys[i] >> lcm::KEY_SHIFT);
+    uint32_t thr = std::max((uint32_t)h->params.ratio * m, (uint32_t)h->params.dist_floor);
+    int k = 0;
+    for (int i = 0; i < nq; ++i) {
+        uint32_t d = keys[i] >> lcm::KEY_SHIFT;
+        if (d <= thr) {
+            out[k].query_idx = i;
+            out[k].train_idx = (int32_t)(keys[i] & lcm::KEY_IDX_MASK);
+            out[k].img_idx = 0;
+            out[k].distance = (float)d;
+            ++k;
+        }
+    }
+    *n_out = k;
+    if (min_dist) *min_dist = (int)m;
+    return LCM_OK;
+}
+
+/* ---- loop search ------------------------------------------------------------------------------------- */
+
+int lcm_loop_test(const lcm_params* p, const lcm_score* s, int n_query_kp, int n_train_kp, double* similarity) {
+    if (similarity) *similarity = 0.0;
+    if (!p || !s) return 0;
+    const int den = std::min(n_query_kp, n_train_kp);
+    if (den <= 0) return 0;
+    const double sim = (double)s->good_count / (double)den;     // README.md:126
+    if (similarity) *similarity = sim;
+    return (sim > p->sim_threshold) && ((long long)s->good_count >= (long long)p->min_matches);   // README.md:123-124
+}
+
+// scores of (query frame at q_rows[q_frame]) against stored slots [0, n_elig)
+static int score_prefix(lcm_handle* h, const uint32_t* q_rows, const int32_t* q_counts, uint32_t q_stride_words,
+                        uint32_t q_frame, int nq, int n_elig, lcm_score* out_scores) {
+    if (n_elig <= 0) return LCM_OK;
+    int rc = wait_db(h); if (rc) return rc;
+    const int chunk = n_elig >= 8192 ? 4 : (n_elig >= 4096 ? 2 : 1);
+    const int n_items = (n_elig + chunk - 1) / chunk;
+    std::vector<lcm::WorkItem> items(n_items);
+    for (int i = 0; i < n_items; ++i) {
+        uint32_t b = (uint32_t)i * chunk;
+        items[i] = {q_frame, b, (uint32_t)std::min(chunk, n_elig - (int)b), b};
+    }
+    rc = ensure_dev(h->d_items, h->d_items_n, (size_t)n_items); if (rc) return rc;
+    rc = ensure_dev(h->d_scores, h->d_scores_n, (size_t)n_elig); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_items, items.data(), sizeof(lcm::WorkItem) * n_items, hipMemcpyHostToDevice, h->stream));
+    lcm::ScoreArgs a{};
+    a.q_rows = q_rows; a.q_counts = q_counts; a.q_stride_words = q_stride_words;
+    a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
+    a.items = h->d_items; a.scores = h->d_scores; a.keys = nullptr; a.keys_stride = 0;
+    a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
+    rc = launch_and_time(h, a, (uint32_t)n_items, nq, false); if (rc) return rc;
+    uint64_t dist = 0, bytes = (uint64_t)nq * 32;
+    for (int s = 0; s < n_elig; ++s) { dist += (uint64_t)nq * h->frames[s].n; bytes += (uint64_t)h->frames[s].n * 32 + 8; }
+    h->info.pairs = (uint64_t)n_elig; h->info.distances = dist; h->info.algo_bytes = bytes;
+    HIP_TRY(hipMemcpyAsync(out_scores, h->d_scores, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return LCM_OK;
+}
+
+int lcm_query_scores(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id,
+                     lcm_score* out_scores, int32_t* out_frame_ids, int* n_out) {
+    if (!h || nq < 0 || !n_out || (nq > 0 && !query)) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    *n_out = 0;
+    if (nq > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+    int rc = set_device(h); if (rc) return rc;
+    const int n_elig = eligible_prefix(h, query_frame_id, h->params.min_gap);
+    if (n_elig == 0) return LCM_OK;
+    if (!out_scores) return fail(LCM_ERR_INVALID_ARG, "out_scores is NULL");
+    rc = upload_rows(h, h->d_qbuf, h->d_qbuf_bytes, query, nq, std::max(nq, 1), false); if (rc) return rc;
+    rc = ensure_dev(h->d_qcounts, h->d_qcounts_n, 1); if (rc) return rc;
+    int32_t nqc = nq;
+    HIP_TRY(hipMemcpyAsync(h->d_qcounts, &nqc, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    rc = score_prefix(h, (const uint32_t*)h->d_qbuf, h->d_qcounts, 0, 0, nq, n_elig, out_scores); if (rc) return rc;
+    if (out_frame_ids) for (int s = 0; s < n_elig; ++s) out_frame_ids[s] = h->frames[s].id;
+    *n_out = n_elig;
+    return LCM_OK;
+}
+
+int lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
+                     lcm_loop_candidate* out, int cap, int* n_out) {
+    if (!h || !n_out || cap < 0) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    *n_out = 0;
+    int rc = set_device(h); if (rc) return rc;
+    const int n_elig = eligible_prefix(h, current_frame_id, h->params.min_gap);
+    int q_kp = n_keypoints;
+    h->h_scores.resize((size_t)std::max(n_elig, 1));
+    if (query) {
+        if (nq < 0) return fail(LCM_ERR_INVALID_ARG, "negative row count");
+        if (q_kp < 0) q_kp = nq;
+        if (n_elig > 0) {
+            int n = 0;
+            rc = lcm_query_scores(h, query, nq, current_frame_id, h->h_scores.data(), nullptr, &n); if (rc) return rc;
+        }
+    } else {
+        // the current frame is already stored: use its device rows as the query
+        int slot = -1;
+        {
+            int lo = 0, hi = (int)h->frames.size();
+            while (lo < hi) { int mid = (lo + hi) / 2; if (h->frames[mid].id < current_frame_id) lo = mid + 1; else hi = mid; }
+            if (lo < (int)h->frames.size() && h->frames[lo].id == current_frame_id) slot = lo;
+        }
+        if (slot < 0) return fail(LCM_ERR_NOT_FOUND, "frame id %d is not stored", current_frame_id);
+        nq = h->frames[slot].n;
+        q_kp = h->frames[slot].n_kp;
+        if (nq > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+        rc = score_prefix(h, (const uint32_t*)h->d_rows, h->d_counts, (uint32_t)h->stride_rows * LCM_DESC_WORDS, (uint32_t)slot, nq,
+                          n_elig, h->h_scores.data());
+        if (rc) return rc;
+    }
+    int k = 0, total = 0;
+    for (int s = 0; s < n_elig; ++s) {
+        double sim;
+        if (lcm_loop_test(&h->params, &h->h_scores[s], q_kp, h->frames[s].n_kp, &sim)) {
+            if (k < cap && out) {
+                out[k].current_frame_id = current_frame_id;
+                out[k].matched_frame_id = h->frames[s].id;
+                out[k].num_matches = (int32_t)h->h_scores[s].good_count;
+                out[k].similarity_score = sim;
+                ++k;
+            }
+            ++total;
+        }
+    }
+    *n_out = k;
+    if (total > k) return fail(LCM_ERR_CAPACITY, "%d loop candidates but room for %d", total, cap);
+    return LCM_OK;
+}
+
+/* ---- bulk all-vs-all --------------------------------------------------------------------------------- */
+
+int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
+                   const int32_t* q_ids, int n_q_frames, int q_stride_rows,
+                   void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets) {
+    if (!h || !n_pairs) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    int rc = set_device(h); if (rc) return rc;
+    const bool self = (d_query_rows == nullptr);
+    std::vector<int32_t> self_ids;
+    if (self) {
+        n_q_frames = (int)h->frames.size();
+        self_ids.resize(n_q_frames);
+        for (int i = 0; i < n_q_frames; ++i) self_ids[i] = h->frames[i].id;
+        q_ids = self_ids.data();
+        q_stride_rows = h->stride_rows;
+    } else if (!d_query_counts || !q_ids || n_q_frames < 0 || q_stride_rows <= 0) {
+        return fail(LCM_ERR_INVALID_ARG, "external query set needs counts, ids and a stride");
+    }
+    if (q_stride_rows > lcm::MAX_FUSED_QUERY_ROWS && !self) return fail(LCM_ERR_CAPACITY, "query frames may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+
+    // ---- plan (cached while the database and the query-id list are unchanged)
+    uint64_t key = mix(mix(mix(0x1234, (uint64_t)h->frames.size()), (uint64_t)n_q_frames), (uint64_t)h->params.min_gap);
+    key = mix(key, self ? 1 : 2);
+    for (int i = 0; i < n_q_frames; ++i) key = mix(key, (uint64_t)(uint32_t)q_ids[i]);
+    if (!h->frames.empty()) key = mix(mix(key, (uint64_t)h->frames.front().id), (uint64_t)h->frames.back().id);
+    if (key == 0) key = 1;
+    Plan& P = h->plan;
+    if (P.key != key) {
+        P.items.clear();
+        P.offsets.assign((size_t)n_q_frames + 1, 0);
+        size_t total = 0;
+        for (int c = 0; c < n_q_frames; ++c) { P.offsets[c] = total; total += (size_t)eligible_prefix(h, q_ids[c], h->params.min_gap); }
+        P.offsets[n_q_frames] = total;
+        if (total > 0xFFFFFFFFull) return fail(LCM_ERR_CAPACITY, "more than 2^32 pairs in one call");
+        const int chunk = pick_chunk(total);
+        P.distances = 0; P.algo_bytes = 0; P.max_q_rows = 0;
+        // prefix sums of stored row counts for the distance / byte accounting
+        std::vector<uint64_t> pre(h->frames.size() + 1, 0);
+        for (size_t s = 0; s < h->frames.size(); ++s) pre[s + 1] = pre[s] + (uint64_t)h->frames[s].n;
+        std::vector<int32_t> qn;
+        if (self) { qn.resize(n_q_frames); for (int i = 0; i < n_q_frames; ++i) qn[i] = h->frames[i].n; }
+        // heaviest query frames first so the tail of the launch is made of short items
+        for (int c = n_q_frames - 1; c >= 0; --c) {
+            const int e = (int)(P.offsets[c + 1] - P.offsets[c]);
+            for (int b = 0; b < e; b += chunk)
+                P.items.push_back({(uint32_t)c, (uint32_t)b, (uint32_t)std::min(chunk, e - b), (uint32_t)(P.offsets[c] + b)});
+            if (self && e > 0) {
+                P.distances += (uint64_t)qn[c] * pre[e];
+                P.algo_bytes += pre[e] * 32 + (uint64_t)qn[c] * 32 + 8ull * e;
+                P.max_q_rows = std::max(P.max_q_rows, (int)qn[c]);
+            }
+        }
+        if (!self) {
+            // row counts of an external query set live on the device: fetch them once per plan
+            std::vector<int32_t> qc((size_t)std::max(n_q_frames, 1));
+            HIP_TRY(hipMemcpy(qc.data(), d_query_counts, sizeof(int32_t) * (size_t)n_q_frames, hipMemcpyDeviceToHost));
+            for (int c = 0; c < n_q_frames; ++c) {
+                const int e = (int)(P.offsets[c + 1] - P.offsets[c]);
+                if (qc[c] < 0 || qc[c] > q_stride_rows) return fail(LCM_ERR_INVALID_ARG, "query frame %d has %d rows, stride %d", c, qc[c], q_stride_rows);
+                if (e > 0) {
+                    P.distances += (uint64_t)qc[c] * pre[e];
+                    P.algo_bytes += pre[e] * 32 + (uint64_t)qc[c] * 32 + 8ull * e;
+                    P.max_q_rows = std::max(P.max_q_rows, (int)qc[c]);
+                }
+            }
+        }
+        if (P.max_q_rows > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "query frames may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+        P.n_pairs = total;
+        if (!P.items.empty()) {
+            rc = ensure_dev(P.d_items, P.d_items_cap, P.items.size()); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(P.d_items, P.items.data(), sizeof(lcm::WorkItem) * P.items.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        P.key = key;
+    }
+    *n_pairs = P.n_pairs;
+    if (pair_offsets) memcpy(pair_offsets, P.offsets.data(), sizeof(size_t) * ((size_t)n_q_frames + 1));
+    if (!d_scores) return LCM_OK;       // sizing call
+    if (scores_cap < P.n_pairs) return fail(LCM_ERR_CAPACITY, "scores buffer holds %zu records, need %zu", scores_cap, P.n_pairs);
+    if (P.n_pairs == 0) return LCM_OK;
+
+    rc = wait_db(h); if (rc) return rc;
+    lcm::ScoreArgs a{};
+    a.q_rows = self ? (const uint32_t*)h->d_rows : (const uint32_t*)d_query_rows;
+    a.q_counts = self ? h->d_counts : d_query_counts;
+    a.q_stride_words = (uint32_t)q_stride_rows * LCM_DESC_WORDS;
+    a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
+    a.items = P.d_items; a.scores = d_scores; a.keys = nullptr; a.keys_stride = 0;
+    a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
+    rc = launch_and_time(h, a, (uint32_t)P.items.size(), P.max_q_rows, false); if (rc) return rc;
+    h->info.pairs = P.n_pairs; h->info.distances = P.distances; h->info.algo_bytes = P.algo_bytes;
+    return LCM_OK;
+}
+
+int lcm_last_launch_info(const lcm_handle* hc, lcm_launch_info* info) {
+    lcm_handle* h = const_cast<lcm_handle*>(hc);
+    if (!h || !info) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    if (h->info_pending) {
+        HIP_TRY(hipEventSynchronize(h->ev_stop));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_stop));
+        h->info.kernel_ms = ms;
+        h->info_pending = false;
+    }
+    *info = h->info;
+    return LCM_OK;
+}
+
+/* ---- device scratch helpers -------------------------------------------------------------------------- */
+
+int lcm_dev_alloc(lcm_handle* h, size_t bytes, void** d_ptr) {
+    if (!h || !d_ptr) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    int rc = set_device(h); if (rc) return rc;
+    HIP_TRY(hipMalloc(d_ptr, std::max<size_t>(bytes, 16)));
+    return LCM_OK;
+}
+int lcm_dev_free(lcm_handle* h, void* d_ptr) {
+    if (!h) return fail(LCM_ERR_INVALID_ARG, "NULL handle");
+    int rc = set_device(h); if (rc) return rc;
+    HIP_TRY(hipFree(d_ptr));
+    return LCM_OK;
+}
+int lcm_dev_upload(lcm_handle* h, void* d_dst, const void* src, size_t bytes) {
+    if (!h || (bytes && (!d_dst || !src))) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    int rc = set_device(h); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return LCM_OK;
+}
+int lcm_dev_download(lcm_handle* h, void* dst, const void* d_src, size_t bytes) {
+    if (!h || (bytes && (!dst || !d_src))) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    int rc = set_device(h); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return LCM_OK;
+}
+
+}  // extern "C"

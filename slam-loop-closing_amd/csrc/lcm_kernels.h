@@ -1,0 +1,41 @@
+// lcm_kernels.h — launch interface between the C-ABI host code (lcm_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lcm {
+
+constexpr int KEY_SHIFT = 22;                       // packed key = dist << 22 | train_idx  (dist <= 256 -> 9 bits)
+constexpr uint32_t KEY_IDX_MASK = (1u << KEY_SHIFT) - 1;
+constexpr int MAX_FUSED_QUERY_ROWS = 2048;          // one workgroup holds a whole query frame in registers
+
+// One unit of work: query frame `q_frame` against stored slots [slot_begin, slot_begin + n_slots),
+// score records written to scores[out_offset ...].
+struct WorkItem {
+    uint32_t q_frame;
+    uint32_t slot_begin;
+    uint32_t n_slots;
+    uint32_t out_offset;
+};
+
+struct ScoreArgs {
+    const uint32_t* q_rows;      // query frames: frame f at q_rows + f * q_stride_words, rows of 8 dwords
+    const int32_t*  q_counts;    // rows per query frame
+    uint32_t        q_stride_words;
+    const uint32_t* db_rows;     // stored frames, same layout
+    const int32_t*  db_counts;
+    uint32_t        db_stride_words;
+    const WorkItem* items;
+    void*           scores;      // lcm_score records (8 bytes each)
+    uint32_t*       keys;        // optional: best packed key per query row, keys[pair * keys_stride + row]
+    uint32_t        keys_stride;
+    int32_t         ratio;
+    int32_t         dist_floor;
+};
+
+// Launch the pair-scoring kernel over n_items work items.  max_query_rows = largest row count of any query
+// frame referenced (<= MAX_FUSED_QUERY_ROWS).  variant: 0 = row-per-lane/scalar-broadcast (default).
+hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
+                        hipStream_t st);
+
+}  // namespace lcm

@@ -1,0 +1,205 @@
+// lcm_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the loop-closure matcher.
+//
+// What is computed (reference: LoopClosingSystem::matchFeatures / detectLoops, include/loop_closing.hpp:40,48;
+// rules README.md:116-126): for one query frame and one stored ("train") frame, every query row's FIRST minimum
+// 256-bit Hamming distance over the train rows (cv::BFMatcher NORM_HAMMING k=1 semantics), then the pair's
+// min-of-mins, the count of matches with d <= max(ratio*min, floor), and one 8-byte lcm_score record.
+//
+// This is integer VALU work: 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 (accumulating) per distance, no MFMA.
+//
+// Variant 0 — "row-per-lane, train rows through the scalar unit":
+//   * every lane OWNS up to QPT query rows in VGPRs (8 dwords each), loaded once per work item with coalesced
+//     16-byte loads (row-major 32-byte rows: lane l reads row l — the 32-byte descriptor database layout);
+//   * the train rows are wave-uniform: they are read with s_load_dwordx16 from the constant address space into
+//     SGPRs and used directly as the scalar operand of v_xor_b32 — no LDS traffic, no VGPRs, no cross-lane work
+//     in the inner loop;
+//   * per-query running minimum is a packed key (dist << 22 | train_idx) folded with v_min3_u32, so the lowest
+//     train index wins ties for free (strict-'<' scan order of OpenCV's batchDistance);
+//   * per pair, the min-of-mins and the good-match count are wavefront shuffle reductions + a 4-entry LDS combine.
+//
+// Variant 1 — "train-row-per-lane, queries staged in LDS" (the mapping BASELINE.json's north_star sketches):
+//   lanes own train rows (coalesced loads), query rows are broadcast from LDS, per-query min/argmin is a
+//   wavefront reduction per query.  Kept for A/B measurement; see DESIGN.md for the numbers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lcm_kernels.h"
+
+namespace lcm {
+
+typedef const uint32_t __attribute__((address_space(4))) * sptr_t;   // constant AS => SMEM (s_load) when uniform
+typedef const int32_t __attribute__((address_space(4))) * siptr_t;
+
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+    return min(min(a, b), c);   // v_min3_u32
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+
+// Hamming distance of a VGPR-resident row against a wave-uniform row held in SGPRs:
+// 8 x v_xor_b32 (scalar src0) + one 8-deep v_bcnt_u32_b32 accumulate chain.  The chain is written as inline
+// asm because hipcc -O3 otherwise re-associates the adds into a tree and spends 3 extra v_add3_u32 per distance.
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ uint32_t bcnt0(uint32_t x) {
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x));
+    return d;
+}
+__device__ __forceinline__ uint32_t ham8(const uint32_t (&q)[8], const uint32_t* s) {
+    uint32_t d = bcnt0(q[0] ^ s[0]);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) d = bcnt_acc(q[k] ^ s[k], d);
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Variant 0
+// ---------------------------------------------------------------------------------------------------
+template <int THREADS, int QPT, bool WRITE_KEYS>
+__global__ __launch_bounds__(THREADS) void k_score_rowlane(ScoreArgs a) {
+    constexpr int WAVES = THREADS / 64;
+    __shared__ uint32_t red_min[2][WAVES];
+    __shared__ uint32_t red_sum[2][WAVES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const WorkItem it = a.items[blockIdx.x];
+    const int nq = a.q_counts[it.q_frame];
+
+    // ---- load this lane's query rows: row = j*THREADS + tid (consecutive lanes -> consecutive 32-byte rows)
+    uint32_t q[QPT][8];
+    bool valid[QPT];
+    {
+        const uint4* qbase = reinterpret_cast<const uint4*>(a.q_rows + (size_t)it.q_frame * a.q_stride_words);
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int row = j * THREADS + tid;
+            valid[j] = row < nq;
+            uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
+            if (valid[j]) { lo = qbase[row * 2]; hi = qbase[row * 2 + 1]; }
+            q[j][0] = lo.x; q[j][1] = lo.y; q[j][2] = lo.z; q[j][3] = lo.w;
+            q[j][4] = hi.x; q[j][5] = hi.y; q[j][6] = hi.z; q[j][7] = hi.w;
+        }
+    }
+
+    for (uint32_t s = 0; s < it.n_slots; ++s) {
+        const uint32_t slot = it.slot_begin + s;
+        const int nt = ((siptr_t)a.db_counts)[slot];
+        sptr_t T = (sptr_t)(a.db_rows + (size_t)slot * a.db_stride_words);
+
+        uint32_t best[QPT];
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) best[j] = 0xFFFFFFFFu;
+
+        // Train rows are stored padded to a multiple of 4 rows with copies of the LAST real row: a copy has the
+        // same distance and a higher index than the row it copies, so it can never win the (dist, idx) minimum.
+        // Two 16-dword SGPR buffers (2 rows each) ping-pong: the s_load of the next 2 rows is in flight while the
+        // VALU works on the current 2 (SMEM returns out of order, so the only legal wait is lgkmcnt(0)).
+        if (nt > 0) {
+            uint32_t A[16], B[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) A[k] = T[k];
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            for (int t = 0; t < nt; t += 4) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) B[k] = T[(t + 2) * 8 + k];
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the VALU block it overlaps
+#pragma unroll
+                for (int j = 0; j < QPT; ++j) {
+                    const uint32_t k0 = (ham8(q[j], A) << KEY_SHIFT) | (uint32_t)t;
+                    const uint32_t k1 = (ham8(q[j], A + 8) << KEY_SHIFT) | (uint32_t)(t + 1);
+                    best[j] = umin3(best[j], k0, k1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): B landed while A was being consumed
+#pragma unroll
+                for (int k = 0; k < 16; ++k) A[k] = T[(t + 4) * 8 + k];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < QPT; ++j) {
+                    const uint32_t k0 = (ham8(q[j], B) << KEY_SHIFT) | (uint32_t)(t + 2);
+                    const uint32_t k1 = (ham8(q[j], B + 8) << KEY_SHIFT) | (uint32_t)(t + 3);
+                    best[j] = umin3(best[j], k0, k1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // A (rows t+4, t+5) landed while B was being consumed
+            }
+        }
+
+        // ---- pair epilogue: min-of-mins, ratio filter count, one score record
+        const size_t out = (size_t)it.out_offset + s;
+        if (WRITE_KEYS) {
+#pragma unroll
+            for (int j = 0; j < QPT; ++j)
+                if (valid[j]) a.keys[out * a.keys_stride + j * THREADS + tid] = best[j];
+        }
+        uint32_t dmin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) if (valid[j]) dmin = min(dmin, best[j] >> KEY_SHIFT);
+        dmin = wave_min(dmin);
+        const int par = s & 1;
+        if (WAVES > 1) {
+            if (lane == 0) red_min[par][wave] = dmin;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) dmin = min(dmin, red_min[par][w]);
+        }
+        uint32_t thr = (uint32_t)a.ratio * dmin;
+        thr = max(thr, (uint32_t)a.dist_floor);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) cnt += (valid[j] && (best[j] >> KEY_SHIFT) <= thr) ? 1u : 0u;
+        cnt = wave_sum(cnt);
+        if (WAVES > 1) {
+            if (lane == 0) red_sum[par][wave] = cnt;
+            __syncthreads();
+            cnt = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) cnt += red_sum[par][w];
+        }
+        if (tid == 0) {
+            const bool empty = (nq <= 0) || (nt <= 0);
+            uint2 rec;
+            rec.x = empty ? 0u : cnt;
+            rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
+            reinterpret_cast<uint2*>(a.scores)[out] = rec;
+        }
+    }
+}
+
+template <int THREADS, int QPT>
+static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool write_keys, hipStream_t st) {
+    if (n_items == 0) return hipSuccess;
+    if (write_keys)
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true>), dim3(n_items), dim3(THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, false>), dim3(n_items), dim3(THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
+                        hipStream_t st) {
+    (void)variant;
+    if (max_query_rows <= 512) return launch_rowlane<64, 8>(a, n_items, write_keys, st);
+    if (max_query_rows <= 1024) return launch_rowlane<128, 8>(a, n_items, write_keys, st);
+    if (max_query_rows <= 1536) return launch_rowlane<192, 8>(a, n_items, write_keys, st);
+    if (max_query_rows <= 2048) return launch_rowlane<256, 8>(a, n_items, write_keys, st);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace lcm

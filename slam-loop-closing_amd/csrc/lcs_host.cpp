@@ -1,0 +1,187 @@
+// lcs_host.cpp — loop_closing::LoopClosingSystem on top of the C ABI, plus its C shim (include/lcm_host.h).
+#include "loop_closing_system.hpp"
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+#include <fstream>
+#include <new>
+
+#include "../../include/lcm_host.h"
+
+namespace loop_closing {
+
+namespace {
+[[noreturn]] void raise(const char* what) {
+    throw std::runtime_error(std::string(what) + ": " + lcm_last_error());
+}
+}  // namespace
+
+LoopClosingSystem::LoopClosingSystem(double loop_threshold, int min_loop_gap, int device_id, int shard_rank, int shard_world)
+    : loop_threshold_(loop_threshold), min_loop_gap_(min_loop_gap), shard_rank_(shard_rank), shard_world_(shard_world) {
+    if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) throw std::invalid_argument("bad shard_rank / shard_world");
+    lcm_params p;
+    lcm_params_default(&p);
+    p.sim_threshold = loop_threshold;
+    p.min_gap = min_loop_gap;
+    if (lcm_create(&p, device_id, nullptr, &matcher_) != LCM_OK) raise("LoopClosingSystem: lcm_create");
+}
+
+LoopClosingSystem::~LoopClosingSystem() { lcm_destroy(matcher_); }
+
+const Frame* LoopClosingSystem::findFrame(int frame_id) const {
+    auto it = std::lower_bound(frames_.begin(), frames_.end(), frame_id, [](const Frame& f, int id) { return f.id < id; });
+    return (it != frames_.end() && it->id == frame_id) ? &*it : nullptr;
+}
+
+void LoopClosingSystem::processFrame(const uint8_t* descriptors, int rows, int num_keypoints, int frame_id) {
+    if (rows < 0 || (rows > 0 && !descriptors)) throw std::invalid_argument("processFrame: bad descriptors");
+    if (!frames_.empty() && frame_id <= frames_.back().id) throw std::invalid_argument("processFrame: frame ids must increase");
+    Frame f;
+    f.id = frame_id;
+    f.num_keypoints = num_keypoints < 0 ? rows : num_keypoints;
+    f.descriptors.assign(descriptors, descriptors + (size_t)rows * 32);
+    // loop-closure check against the frames stored so far (the current frame is the query, README.md:100,122) ...
+    frames_.push_back(std::move(f));
+    std::vector<LoopCandidate> found = detectLoops(frame_id);
+    loop_closures_.insert(loop_closures_.end(), found.begin(), found.end());
+    // ... then the frame joins the device database if this rank owns its position
+    const size_t pos = frames_.size() - 1;
+    if (ownsPosition(pos)) {
+        const Frame& s = frames_.back();
+        if (lcm_db_append(matcher_, s.id, s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_db_append");
+    }
+}
+
+std::vector<DMatch> LoopClosingSystem::matchFeatures(const Frame& frame1, const Frame& frame2) {
+    static_assert(sizeof(DMatch) == sizeof(lcm_dmatch), "DMatch layout");
+    std::vector<DMatch> out((size_t)std::max(frame1.rows(), 1));
+    int n = 0, md = 0;
+    if (lcm_match_features(matcher_, frame1.descriptors.data(), frame1.rows(), frame2.descriptors.data(), frame2.rows(),
+                           reinterpret_cast<lcm_dmatch*>(out.data()), &n, &md) != LCM_OK)
+        raise("matchFeatures");
+    out.resize((size_t)n);
+    return out;
+}
+
+std::vector<LoopCandidate> LoopClosingSystem::detectLoops(int current_frame_id) {
+    static_assert(sizeof(LoopCandidate) == sizeof(lcm_loop_candidate), "LoopCandidate layout");
+    const Frame* cur = findFrame(current_frame_id);
+    if (!cur) throw std::out_of_range("detectLoops: unknown frame id");
+    const int cap = std::max(lcm_db_size(matcher_), 1);
+    std::vector<LoopCandidate> out((size_t)cap);
+    int n = 0;
+    static const uint8_t dummy[32] = {0};
+    const uint8_t* q = cur->rows() > 0 ? cur->descriptors.data() : dummy;
+    if (lcm_detect_loops(matcher_, current_frame_id, q, cur->rows(), cur->num_keypoints,
+                         reinterpret_cast<lcm_loop_candidate*>(out.data()), cap, &n) != LCM_OK)
+        raise("detectLoops");
+    out.resize((size_t)n);
+    return out;
+}
+
+void LoopClosingSystem::saveResults(const std::string& output_dir) {
+    if (mkdir(output_dir.c_str(), 0777) != 0 && errno != EEXIST)
+        throw std::runtime_error("saveResults: cannot create " + output_dir + ": " + strerror(errno));
+    const std::string path = output_dir + "/loop_closures.txt";
+    std::ofstream os(path);
+    if (!os) throw std::runtime_error("saveResults: cannot open " + path);
+    // README.md:150-166
+    os << "=== Processing Complete ===\n";
+    os << "Total frames processed: " << frames_.size() << "\n";
+    os << "Loop closures detected: " << loop_closures_.size() << "\n\n";
+    os << "Loop Closures Detected:\n======================\n\n";
+    for (const LoopCandidate& c : loop_closures_) {
+        os << "Frame " << c.current_frame_id << " <-> Frame " << c.matched_frame_id << "\n";
+        os << "  Matches: " << c.num_matches << "\n";
+        os << "  Similarity: " << c.similarity_score << "\n\n";
+    }
+    if (!os) throw std::runtime_error("saveResults: write failed: " + path);
+}
+
+}  // namespace loop_closing
+
+// ---------------------------------------------------------------------------------------------------------
+// C shim
+// ---------------------------------------------------------------------------------------------------------
+struct lcs_system {
+    loop_closing::LoopClosingSystem sys;
+    std::string err;
+    lcs_system(double thr, int gap, int dev, int r, int w) : sys(thr, gap, dev, r, w) {}
+};
+
+namespace {
+thread_local std::string g_host_err;
+template <typename F>
+int guarded(F&& f) {
+    try { f(); return LCM_OK; }
+    catch (const std::invalid_argument& e) { g_host_err = e.what(); return LCM_ERR_INVALID_ARG; }
+    catch (const std::out_of_range& e) { g_host_err = e.what(); return LCM_ERR_NOT_FOUND; }
+    catch (const std::bad_alloc&) { g_host_err = "out of memory"; return LCM_ERR_OOM; }
+    catch (const std::exception& e) { g_host_err = e.what(); return LCM_ERR_HIP; }
+}
+}  // namespace
+
+extern "C" {
+
+int lcs_create(double loop_threshold, int min_loop_gap, int device_id, int shard_rank, int shard_world, lcs_system** out) {
+    if (!out) return LCM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (lcm_device_count() <= 0) {
+        lcm_handle* probe = nullptr;
+        return lcm_create(nullptr, device_id, nullptr, &probe);   // sets the "no device, no CPU fallback" message
+    }
+    return guarded([&] { *out = new lcs_system(loop_threshold, min_loop_gap, device_id, shard_rank, shard_world); });
+}
+void lcs_destroy(lcs_system* s) { delete s; }
+
+int lcs_process_frame(lcs_system* s, const uint8_t* desc, int rows, int n_keypoints, int frame_id) {
+    if (!s) return LCM_ERR_INVALID_ARG;
+    return guarded([&] { s->sys.processFrame(desc, rows, n_keypoints, frame_id); });
+}
+
+int lcs_match_features(lcs_system* s, int frame1_id, int frame2_id, lcm_dmatch* out, int cap, int* n_out) {
+    if (!s || !n_out) return LCM_ERR_INVALID_ARG;
+    *n_out = 0;
+    return guarded([&] {
+        const loop_closing::Frame* a = s->sys.findFrame(frame1_id);
+        const loop_closing::Frame* b = s->sys.findFrame(frame2_id);
+        if (!a || !b) throw std::out_of_range("matchFeatures: unknown frame id");
+        auto m = s->sys.matchFeatures(*a, *b);
+        if ((int)m.size() > cap) throw std::invalid_argument("matchFeatures: output buffer too small");
+        if (!m.empty()) memcpy(out, m.data(), m.size() * sizeof(lcm_dmatch));
+        *n_out = (int)m.size();
+    });
+}
+
+int lcs_detect_loops(lcs_system* s, int current_frame_id, lcm_loop_candidate* out, int cap, int* n_out) {
+    if (!s || !n_out) return LCM_ERR_INVALID_ARG;
+    *n_out = 0;
+    return guarded([&] {
+        auto c = s->sys.detectLoops(current_frame_id);
+        if ((int)c.size() > cap) throw std::invalid_argument("detectLoops: output buffer too small");
+        if (!c.empty()) memcpy(out, c.data(), c.size() * sizeof(lcm_loop_candidate));
+        *n_out = (int)c.size();
+    });
+}
+
+int lcs_num_frames(const lcs_system* s) { return s ? (int)s->sys.getFrames().size() : 0; }
+int lcs_num_loop_closures(const lcs_system* s) { return s ? (int)s->sys.getLoopClosures().size() : 0; }
+
+int lcs_get_loop_closures(const lcs_system* s, lcm_loop_candidate* out, int cap, int* n_out) {
+    if (!s || !n_out) return LCM_ERR_INVALID_ARG;
+    const auto& v = s->sys.getLoopClosures();
+    if ((int)v.size() > cap) return LCM_ERR_CAPACITY;
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(lcm_loop_candidate));
+    *n_out = (int)v.size();
+    return LCM_OK;
+}
+
+int lcs_save_results(lcs_system* s, const char* output_dir) {
+    if (!s || !output_dir) return LCM_ERR_INVALID_ARG;
+    return guarded([&] { s->sys.saveResults(output_dir); });
+}
+
+}  // extern "C"

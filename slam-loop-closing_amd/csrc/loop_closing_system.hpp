@@ -1,0 +1,90 @@
+// loop_closing_system.hpp — host-side mirror of the reference's loop_closing::LoopClosingSystem
+// (include/loop_closing.hpp:9-82) for the ORB/Hamming hot path, free of OpenCV types so it builds in an image
+// without OpenCV.  Same class / method names, same argument meaning, same error behaviour (exceptions derived
+// from std::exception, which the reference's main() catches: src/main.cpp:1043,1680).  Everything that computes
+// a Hamming distance goes through the C ABI (include/lcm.h) into the gfx950 kernels.
+//
+// What differs from the reference header, and why:
+//   * Frame::descriptors is a byte vector (rows x 32, row-major) instead of cv::Mat(CV_8UC1); Frame::num_keypoints
+//     replaces keypoints.size().  image / pose / points3D are not on this path and are not stored.
+//   * processFrame takes the descriptors ORB would have produced: feature detection (detectFeatures, hpp:37) is
+//     outside the hot path.
+//   * estimatePose / triangulatePoints / visualizeMatches are out of scope and absent.
+// With OpenCV available, adapters/opencv/loop_closing.cpp defines the reference header's own members on top of this.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct lcm_handle;
+
+namespace loop_closing {
+
+// cv::DMatch field order (consumed as m.queryIdx / m.trainIdx at src/main.cpp:553-554).
+struct DMatch {
+    int queryIdx;
+    int trainIdx;
+    int imgIdx;
+    float distance;
+};
+
+struct Frame {                       // include/loop_closing.hpp:12-19, hot-path fields only
+    int id = 0;
+    int num_keypoints = 0;           // keypoints.size(): denominator of the similarity score (README.md:126)
+    std::vector<uint8_t> descriptors;  // rows x 32 bytes
+    int rows() const { return (int)(descriptors.size() / 32); }
+};
+
+struct LoopCandidate {               // include/loop_closing.hpp:22-27, identical
+    int current_frame_id;
+    int matched_frame_id;
+    int num_matches;
+    double similarity_score;
+};
+
+class LoopClosingSystem {
+public:
+    // include/loop_closing.hpp:31 — same defaults.  device_id / shard_* are additions with defaults that keep the
+    // reference's two-argument construction valid.
+    explicit LoopClosingSystem(double loop_threshold = 0.7, int min_loop_gap = 30, int device_id = 0,
+                               int shard_rank = 0, int shard_world = 1);
+    ~LoopClosingSystem();
+    LoopClosingSystem(const LoopClosingSystem&) = delete;
+    LoopClosingSystem& operator=(const LoopClosingSystem&) = delete;
+
+    // Process a single frame (hpp:34): store it, then check for loop closures (README.md:94-100).
+    void processFrame(const uint8_t* descriptors, int rows, int num_keypoints, int frame_id);
+
+    // Match features between two frames (hpp:40): BFMatcher(NORM_HAMMING).match + 2 x min-distance filter.
+    std::vector<DMatch> matchFeatures(const Frame& frame1, const Frame& frame2);
+
+    // Check for loop closure (hpp:48): current frame vs every stored frame >= min_loop_gap older.
+    std::vector<LoopCandidate> detectLoops(int current_frame_id);
+    // BASELINE.json's north_star spells this one detectLoopClosure.
+    std::vector<LoopCandidate> detectLoopClosure(int current_frame_id) { return detectLoops(current_frame_id); }
+
+    const std::vector<Frame>& getFrames() const { return frames_; }                      // hpp:60
+    const std::vector<LoopCandidate>& getLoopClosures() const { return loop_closures_; }  // hpp:63
+
+    // Save results to file (hpp:66): writes <output_dir>/loop_closures.txt in the README's format (README.md:142-165).
+    void saveResults(const std::string& output_dir);
+
+    double loopThreshold() const { return loop_threshold_; }
+    int minLoopGap() const { return min_loop_gap_; }
+    const Frame* findFrame(int frame_id) const;
+    bool ownsPosition(size_t position) const { return (int)(position % (size_t)shard_world_) == shard_rank_; }
+
+private:
+    std::vector<Frame> frames_;
+    std::vector<LoopCandidate> loop_closures_;
+    lcm_handle* matcher_ = nullptr;      // stands where cv::Ptr<cv::BFMatcher> matcher_ stood (hpp:73)
+    double loop_threshold_;              // hpp:75
+    int min_loop_gap_;                   // hpp:76
+    int shard_rank_, shard_world_;
+};
+
+using LoopClosing = LoopClosingSystem;   // north_star's spelling of the class
+
+}  // namespace loop_closing

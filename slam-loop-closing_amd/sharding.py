@@ -1,0 +1,97 @@
+"""Frame-sharded multi-GPU loop search: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in CPU tests) for the one real exchange step — gathering per-shard score records.
+
+Partitioning: the stored-frame database is sharded cyclically by frame — stored frame with
+position i (ascending id) is OWNED by rank i mod W.  Cyclic rather than blocked because the all-vs-all workload is
+triangular (a query only meets frames >= min_gap older) and, in streaming mode, the database grows: blocks would
+leave the first rank idle early and the last overloaded.  Every rank sees every QUERY frame (each frame is a query
+exactly once; 64 KB), scores it against the frames it owns with no communication, and the 8-byte score records
+(good_count, min_dist, n_train) are then all-gathered and un-permuted into ascending stored-frame order, so the
+merged result is byte-identical to the single-GPU result.
+
+This module holds only the host logic (ownership, offsets, merge, gather).  The scoring itself is whatever
+`Matcher`-like object the caller passes in: the HIP library in production, the CPU oracle in the world_size-2
+gloo tests that cover this logic without a GPU.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+SCORE_DTYPE = np.dtype([("good_count", "<u4"), ("min_dist", "<u2"), ("n_train", "<u2")])
+
+
+def owner_of(position: int, world: int) -> int:
+    return position % world
+
+
+def owned_positions(n_frames: int, rank: int, world: int) -> np.ndarray:
+    return np.arange(rank, n_frames, world, dtype=np.int64)
+
+
+def eligible_counts(ids: Sequence[int], gap: int) -> np.ndarray:
+    """e[c] = number of stored frames i with ids[c] - ids[i] >= max(gap, 1); ids strictly increasing."""
+    ids = np.asarray(ids, np.int64)
+    return np.searchsorted(ids, ids - max(int(gap), 1), side="right").astype(np.int64)
+
+
+def shard_eligible_counts(ids: Sequence[int], gap: int, rank: int, world: int) -> np.ndarray:
+    """Same, counting only the frames owned by `rank`: positions rank, rank + W, ... below e[c]."""
+    e = eligible_counts(ids, gap)
+    return np.maximum(0, (e - rank + world - 1) // world).astype(np.int64)
+
+
+def offsets_from_counts(counts: np.ndarray) -> np.ndarray:
+    offs = np.zeros(len(counts) + 1, np.int64)
+    np.cumsum(counts, out=offs[1:])
+    return offs
+
+
+def merge_shard_scores(shard_scores: List[np.ndarray], ids: Sequence[int], gap: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Un-permute per-rank score arrays (each in (query asc, owned stored asc) order) into the single-device
+    (query asc, stored asc) order.  Returns (scores, offsets[n_frames + 1])."""
+    world = len(shard_scores)
+    e = eligible_counts(ids, gap)
+    offs = offsets_from_counts(e)
+    out = np.zeros(int(offs[-1]), SCORE_DTYPE)
+    n = len(e)
+    for r in range(world):
+        er = np.maximum(0, (e - r + world - 1) // world)
+        offr = offsets_from_counts(er)
+        src = np.asarray(shard_scores[r])
+        if int(offr[-1]) != src.shape[0]:
+            raise ValueError(f"rank {r}: expected {int(offr[-1])} score records, got {src.shape[0]}")
+        if src.shape[0] == 0:
+            continue
+        # destination index of every record of this shard, vectorised: for query c, k-th owned -> offs[c] + r + k*W
+        c_of = np.repeat(np.arange(n), er)
+        k_of = np.arange(src.shape[0]) - offr[c_of]
+        out[offs[c_of] + r + k_of * world] = src
+    return out, offs
+
+
+def all_gather_scores(local: "torch.Tensor", n_local: int, group=None) -> List[np.ndarray]:  # noqa: F821
+    """All-gather variable-length score arrays.  `local` is an int64 tensor viewing 8-byte records (device tensor
+    for nccl/RCCL, CPU tensor for gloo) holding at least n_local records.  One fixed-size all_gather of the padded
+    payload (shard sizes differ by at most one frame's worth, so padding is negligible) plus one of the lengths."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n_t = torch.tensor([n_local], dtype=torch.int64, device=local.device)
+    lens = [torch.zeros_like(n_t) for _ in range(world)]
+    dist.all_gather(lens, n_t, group=group)
+    lens = [int(x.item()) for x in lens]
+    cap = max(max(lens), 1)
+    if local.numel() < cap:
+        pad = torch.zeros(cap, dtype=torch.int64, device=local.device)
+        pad[:n_local] = local[:n_local]
+        send = pad
+    else:
+        send = local[:cap].contiguous()
+    recv = torch.empty(world * cap, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(recv, send, group=group) if hasattr(dist, "all_gather_into_tensor") and local.is_cuda \
+        else dist.all_gather(list(recv.view(world, cap).unbind(0)), send, group=group)
+    host = recv.view(world, cap).cpu().numpy()
+    return [host[r, : lens[r]].view(SCORE_DTYPE).copy() for r in range(world)]

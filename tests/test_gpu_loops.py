@@ -1,0 +1,162 @@
+"""Database / loop-search entry points vs the oracle: lcm_query_scores, lcm_detect_loops, lcm_all_vs_all,
+streaming append, sharded == single."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def fill(m, fs, positions=None):
+    m.clear()
+    for f in (range(fs.n_frames) if positions is None else positions):
+        m.append(int(fs.ids[f]), fs.frame(f))
+
+
+def gpu_all_vs_all(m, fs=None, q_ids=None, d_rows=0, d_counts=0, stride=0):
+    n, offs = m.all_vs_all_plan(d_rows, d_counts, q_ids, stride)
+    d_scores = m.dev_alloc(max(n, 1) * 8)
+    try:
+        got = m.all_vs_all(d_scores, n, d_rows, d_counts, q_ids, stride)
+        assert got == n
+        out = np.zeros(max(n, 1), m_score_dtype(m))
+        m.sync()
+        m.dev_download(d_scores, out)
+    finally:
+        m.dev_free(d_scores)
+    return out[:n], offs
+
+
+def m_score_dtype(m):
+    from conftest import load_package
+    return load_package().capi.SCORE_DTYPE
+
+
+@pytest.mark.parametrize("n_frames,max_desc,gap,ragged", [(100, 500, 30, False), (40, 300, 5, True), (12, 2000, 3, True)])
+def test_all_vs_all_bit_exact(matcher, oracle, pkg, n_frames, max_desc, gap, ragged):
+    """cfg1 (100 x 500, gap 30) is BASELINE.json's configs[0]; the others stress ragged / full-size frames."""
+    fs = pkg.synth.make_frames(n_frames, max_desc, seed=pkg.synth.BASE_SEED + 1, ragged=ragged, dup_frac=0.2)
+    if ragged:
+        fs.counts[2] = 0
+    matcher.set_params(min_gap=gap)
+    try:
+        fill(matcher, fs)
+        got, offs = gpu_all_vs_all(matcher)
+        want, woffs = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap))
+        np.testing.assert_array_equal(offs, woffs)
+        np.testing.assert_array_equal(got, want)
+        assert len(got) == pkg.synth.n_pairs_all_vs_all(n_frames, gap)
+        info = matcher.launch_info()
+        assert info.pairs == len(got) and info.kernel_ms > 0
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
+
+
+def test_query_scores_and_detect_loops(matcher, oracle, pkg):
+    fs = pkg.synth.make_frames(64, 256, seed=4, ragged=True, dup_frac=0.3)
+    matcher.set_params(min_gap=7)
+    p = oracle.default_params(min_gap=7)
+    try:
+        fill(matcher, fs)
+        for cur in (0, 6, 7, 8, 33, 63):
+            scores, ids = matcher.query_scores(fs.frame(cur), int(fs.ids[cur]))
+            want = [oracle.pair_score(fs.frame(cur), fs.frame(i), p) for i in range(fs.n_frames)
+                    if fs.ids[cur] - fs.ids[i] >= 7]
+            assert len(scores) == len(want)
+            assert ids.tolist() == [int(fs.ids[i]) for i in range(fs.n_frames) if fs.ids[cur] - fs.ids[i] >= 7]
+            for a, b in zip(scores, want):
+                assert a == b
+            # detectLoops on the stored frame and on an explicitly passed frame agree with the oracle
+            want_c = oracle.detect_loops(fs.rows, fs.counts, fs.ids, cur, p)
+            for got_c in (matcher.detect_loops(int(fs.ids[cur])), matcher.detect_loops(int(fs.ids[cur]), fs.frame(cur))):
+                assert len(got_c) == len(want_c)
+                for f in ("current_frame_id", "matched_frame_id", "num_matches", "similarity_score"):
+                    np.testing.assert_array_equal(got_c[f], want_c[f])
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
+
+
+def test_detect_loops_finds_revisits(matcher, oracle, pkg):
+    """Place-structured data must yield real loop candidates, otherwise the test above compares empty lists."""
+    fs = pkg.synth.make_frames(48, 600, seed=21)
+    matcher.set_params(min_gap=10)
+    try:
+        fill(matcher, fs)
+        total = 0
+        for cur in range(10, 48):
+            want = oracle.detect_loops(fs.rows, fs.counts, fs.ids, cur, oracle.default_params(min_gap=10))
+            got = matcher.detect_loops(int(fs.ids[cur]))
+            np.testing.assert_array_equal(got["matched_frame_id"], want["matched_frame_id"])
+            np.testing.assert_array_equal(got["num_matches"], want["num_matches"])
+            np.testing.assert_array_equal(got["similarity_score"], want["similarity_score"])
+            total += len(got)
+        assert total > 0
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
+
+
+def test_streaming_append_equals_batch(matcher, oracle, pkg):
+    """Online mode: append frame, query the next one, append it, ... == the all-vs-all batch result."""
+    fs = pkg.synth.make_frames(50, 320, seed=13, ragged=True)
+    gap = 4
+    matcher.set_params(min_gap=gap)
+    try:
+        matcher.clear()
+        online = []
+        for f in range(fs.n_frames):
+            s, _ = matcher.query_scores(fs.frame(f), int(fs.ids[f]))
+            online.append(s.copy())
+            matcher.append(int(fs.ids[f]), fs.frame(f))
+        online = np.concatenate(online)
+        want, _ = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap))
+        np.testing.assert_array_equal(online, want)
+        # and the stored rows read back unchanged
+        for slot in (0, 17, 49):
+            np.testing.assert_array_equal(matcher.read_frame(slot), fs.frame(slot))
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
+
+
+def test_sharded_equals_single(matcher, oracle, pkg):
+    """K10: cyclic shards scored one after another on the one GPU, merged on the host == single-device result."""
+    fs = pkg.synth.make_frames(45, 200, seed=17, ragged=True)
+    gap, world = 5, 4
+    matcher.set_params(min_gap=gap)
+    d_rows = matcher.dev_alloc(fs.rows.nbytes)
+    d_counts = matcher.dev_alloc(fs.counts.nbytes)
+    try:
+        matcher.dev_upload(d_rows, fs.rows)
+        matcher.dev_upload(d_counts, fs.counts)
+        fill(matcher, fs)
+        single, offs = gpu_all_vs_all(matcher)
+        shards = []
+        for r in range(world):
+            fill(matcher, fs, pkg.sharding.owned_positions(fs.n_frames, r, world))
+            s, _ = gpu_all_vs_all(matcher, q_ids=fs.ids, d_rows=d_rows, d_counts=d_counts, stride=fs.stride_rows)
+            shards.append(s)
+            want_r, _ = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap), r, world)
+            np.testing.assert_array_equal(s, want_r)
+        merged, moffs = pkg.sharding.merge_shard_scores(shards, fs.ids, gap)
+        np.testing.assert_array_equal(merged, single)
+        np.testing.assert_array_equal(moffs, offs.astype(np.int64))
+    finally:
+        matcher.dev_free(d_rows); matcher.dev_free(d_counts)
+        matcher.set_params(min_gap=30)
+        matcher.clear()
+
+
+def test_errors_are_loud(matcher, pkg):
+    matcher.clear()
+    matcher.append(5, np.zeros((3, 32), np.uint8))
+    with pytest.raises(pkg.LcmError) as e:
+        matcher.append(5, np.zeros((3, 32), np.uint8))
+    assert e.value.code == -5                                   # LCM_ERR_ORDER
+    with pytest.raises(pkg.LcmError) as e:
+        matcher.detect_loops(1234)
+    assert e.value.code == -6                                   # LCM_ERR_NOT_FOUND
+    with pytest.raises(pkg.LcmError):
+        matcher.query_scores(np.zeros((2049, 32), np.uint8), 100)
+    matcher.clear()

@@ -1,0 +1,62 @@
+"""C oracle vs an independently written numpy restatement, and tuned CPU baseline vs golden oracle."""
+import numpy as np
+import pytest
+
+from npref import bf_match, pair_score
+
+
+@pytest.mark.parametrize("nq,nt,seed", [(1, 1, 0), (64, 65, 1), (37, 300, 2), (257, 129, 3), (5, 1, 4), (1, 200, 5)])
+def test_bf_match_matches_numpy(oracle, nq, nt, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    # plant ties and duplicates
+    if nt > 4:
+        t[nt - 1] = t[0]
+        t[nt // 2] = t[1]
+        q[0] = t[0]
+    i1, d1 = oracle.bf_match(q, t)
+    i2, d2 = bf_match(q, t)
+    np.testing.assert_array_equal(i1, i2)
+    np.testing.assert_array_equal(d1, d2)
+    s = oracle.pair_score(q, t)
+    assert (int(s["good_count"]), int(s["min_dist"]), int(s["n_train"])) == pair_score(q, t)
+
+
+def test_low_entropy_rows_many_ties(oracle):
+    rng = np.random.default_rng(11)
+    # rows drawn from a tiny alphabet: almost every minimum is tied several times
+    alphabet = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    q = alphabet[rng.integers(0, 6, 90)]
+    t = alphabet[rng.integers(0, 6, 140)]
+    i1, d1 = oracle.bf_match(q, t)
+    i2, d2 = bf_match(q, t)
+    np.testing.assert_array_equal(i1, i2)
+    np.testing.assert_array_equal(d1, d2)
+
+
+def test_fast_baseline_equals_golden(oracle, pkg):
+    fs = pkg.synth.make_frames(12, 150, seed=77, ragged=True, dup_frac=0.5)
+    fs.counts[3] = 0                                            # an empty frame in the mix
+    p = oracle.default_params(min_gap=2)
+    golden, offs = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, p)
+    pq, pt = [], []
+    for c in range(fs.n_frames):
+        for i in range(fs.n_frames):
+            if fs.ids[c] - fs.ids[i] >= 2:
+                pq.append(c); pt.append(i)
+    for threads in (1, 3):
+        fast, secs, isa = oracle.fast_score_pairs(fs.rows, fs.counts, pq, pt, p, n_threads=threads)
+        assert isa in ("avx512-vpopcntdq", "popcnt64")
+        np.testing.assert_array_equal(fast, golden)
+
+
+def test_all_vs_all_shards_partition_the_pairs(oracle, pkg):
+    fs = pkg.synth.make_frames(20, 40, seed=5)
+    p = oracle.default_params(min_gap=3)
+    full, offs = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, p)
+    shards = [oracle.all_vs_all(fs.rows, fs.counts, fs.ids, p, r, 3)[0] for r in range(3)]
+    assert sum(len(s) for s in shards) == len(full)
+    merged, moffs = pkg.sharding.merge_shard_scores(shards, fs.ids, 3)
+    np.testing.assert_array_equal(merged, full)
+    np.testing.assert_array_equal(moffs, offs.astype(np.int64))
