@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — Hamming distances/sec of the all-vs-all loop search (BASELINE.json's metric) on N MI355X GPUs.
+
+One "step" = one full pass of the hot path over the workload: every frame as query against every stored frame at
+least min_gap older (lcm_all_vs_all -> the gfx950 pair-scoring kernel), inputs resident in HBM, followed — for N > 1 —
+by the RCCL all-gather of the per-shard 8-byte score records (the path's one real exchange step).
+
+  N = 1 : BASELINE.json configs[1] — 1000 frames x 2000 x 256-bit descriptors, min_gap 30 (470,935 pairs,
+          1.88e12 distances per step).
+  N > 1 : weak scaling — the frame count is raised so that every rank still scores ~470,935 pairs per step; the
+          stored frames are sharded cyclically by frame (rank = position mod N), every rank sees every query frame.
+          (`--workload cfg3` runs BASELINE.json configs[2], 10000 x 2000, instead.)
+
+Prints ONE JSON line (rank 0).  `roofline` is the HBM view the contract asks for (algorithmic bytes / kernel time);
+`roofline_valu` is the roofline that actually binds this integer path;
+`cpu_baseline` is the oracle's tuned CPU path timed on this box's host cores on a bounded sample of the same pairs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "Hamming distances/sec (256-bit ORB) for all-vs-all loop search, 1/2/4/8 GPUs"
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU roofline of the 16-instruction minimum (8 v_xor_b32 + 8 v_bcnt_u32_b32 per distance), from the measured
+# issue costs on gfx950 (tools/valu_peak.hip, profiles/r01_valu_peak.txt): v_xor_b32 2 cycles and v_bcnt_u32_b32
+# 4 cycles per wave64 instruction per SIMD => 48 SIMD-cycles per 64 distances; 256 CUs x 4 SIMDs at 2.4 GHz.
+VALU_PEAK_DIST_PER_S = 256 * 4 * 64 / 48.0 * 2.4e9
+
+WORKLOADS = {
+    # name: (frames, descriptors per frame, description)
+    "cfg1": (100, 500, "cfg1: 100 frames x 500 x 256-bit descriptors (reference's CPU-runnable plumbing case)"),
+    "cfg2": (1000, 2000, "cfg2: 1000 frames x 2000 x 256-bit ORB descriptors, all-vs-all loop search, min_gap 30"),
+    "cfg3": (10000, 2000, "cfg3: 10000 frames x 2000 descriptors, database sharded by frame across the GPUs"),
+    "cfg4": (5000, 2000, "cfg4: 5000 frames x 2000 descriptors, fused on-device filter + loop-test counts"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="auto", help="auto | cfg1 | cfg2 | cfg3 | cfg4")
+    ap.add_argument("--frames", type=int, default=0, help="override the frame count")
+    ap.add_argument("--desc", type=int, default=0, help="override descriptors per frame")
+    ap.add_argument("--gap", type=int, default=30)
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (A/B measurement)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget; 0 disables")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    args = ap.parse_args()
+
+    import torch  # first: the process then has ONE HIP runtime (torch's), which liblcm_hip.so binds to
+    import torch.distributed as dist
+
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the matcher has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload ------------------------------------------------------------------------------------
+    wl = args.workload
+    if wl == "auto":
+        wl = "cfg2"
+    base_frames, n_desc, wl_desc = WORKLOADS[wl]
+    n_desc = args.desc or n_desc
+    if args.frames:
+        n_frames = args.frames
+    elif args.workload == "auto" and world > 1:
+        per_rank = pkg.synth.n_pairs_all_vs_all(base_frames, args.gap)
+        n_frames = pkg.synth.frames_for_pairs(per_rank * world, args.gap)     # weak scaling
+        wl_desc = (f"cfg2 weak-scaled to {world} GPUs: {n_frames} frames x {n_desc} descriptors "
+                   f"(~{per_rank} pairs per rank per step), cyclic frame sharding, min_gap {args.gap}")
+    else:
+        n_frames = base_frames
+    seed = pkg.synth.BASE_SEED + 2
+    fs = pkg.synth.make_frames(n_frames, n_desc, seed=seed)
+
+    # ---- inputs resident in HBM ----------------------------------------------------------------------
+    d_rows = torch.from_numpy(fs.rows).to(dev)                 # (frames, stride, 32) uint8: the query stream
+    d_counts = torch.from_numpy(fs.counts).to(dev)
+    stream = torch.cuda.current_stream(dev)
+    p = pkg.default_params()
+    p.min_gap = args.gap
+    m = pkg.Matcher(p, device=local_rank, stream=stream.cuda_stream)
+    m.set_kernel_variant(args.variant)
+    owned = pkg.sharding.owned_positions(n_frames, rank, world)
+    m.reserve(len(owned), n_desc)
+    frame_bytes = fs.stride_rows * 32
+    for pos in owned:
+        m.append_device(int(fs.ids[pos]), d_rows.data_ptr() + int(pos) * frame_bytes, int(fs.counts[pos]))
+    if world == 1:
+        n_local, offs = m.all_vs_all_plan()
+        q_args = dict()
+    else:
+        q_args = dict(d_query_rows=d_rows.data_ptr(), d_query_counts=d_counts.data_ptr(), q_ids=fs.ids,
+                      q_stride_rows=fs.stride_rows)
+        n_local, offs = m.all_vs_all_plan(**q_args)
+    scores = torch.zeros(max(n_local, 1), dtype=torch.int64, device=dev)     # 8-byte lcm_score records
+    if world > 1:
+        n_t = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        lens = [torch.zeros_like(n_t) for _ in range(world)]
+        dist.all_gather(lens, n_t)
+        lens = [int(x.item()) for x in lens]
+        cap = max(lens)
+        send = torch.zeros(cap, dtype=torch.int64, device=dev)
+        recv = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    else:
+        lens = [n_local]
+
+    def step():
+        if world == 1:
+            m.all_vs_all(scores.data_ptr(), n_local, **q_args)
+        else:
+            m.all_vs_all(send.data_ptr(), cap, **q_args)          # kernel writes straight into the send buffer
+            dist.all_gather_into_tensor(recv, send)               # RCCL over xGMI: per-shard score records
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # (reading the previous launch's HIP events would sync; collect after the timed region instead)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    info = m.launch_info()                                        # HIP events around the LAST step's kernel
+    kernel_ms.append(info.kernel_ms)
+    # a few more individually timed launches for a stable per-launch duration (outside the timed region)
+    for _ in range(min(3, max(args.steps - 1, 0))):
+        m.all_vs_all((send if world > 1 else scores).data_ptr(), cap if world > 1 else n_local, **q_args)
+        kernel_ms.append(m.launch_info().kernel_ms)
+    kern_ms = float(np.mean(kernel_ms))
+
+    local_dist = int(info.distances)
+    tot = torch.tensor([local_dist, int(info.pairs), int(info.algo_bytes)], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    total_dist, total_pairs, total_bytes = (int(x) for x in tot.tolist())
+    value = total_dist * args.steps / elapsed
+
+    # ---- parity spot check + CPU baseline (rank 0, N = 1 only) ---------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        oracle = entry.load_oracle()
+        oracle.build()
+        threads = args.cpu_threads or (os.cpu_count() or 1)
+        rng = np.random.default_rng(123)
+        got = np.zeros(n_local, pkg.capi.SCORE_DTYPE)
+        torch.cuda.synchronize(dev)
+        got[:] = scores.cpu().numpy().view(pkg.capi.SCORE_DTYPE)[:n_local]
+        qs = rng.integers(args.gap, n_frames, size=4096)
+        ts = np.array([rng.integers(0, q - args.gap + 1) for q in qs])
+        op = oracle.default_params(min_gap=args.gap)
+        # calibrate on a few pairs, then size the sample for ~cpu_seconds of CPU work
+        n_cal = min(4 * threads, len(qs))
+        _, secs, isa = oracle.fast_score_pairs(fs.rows, fs.counts, qs[:n_cal], ts[:n_cal], op, threads)
+        n_s = int(min(len(qs), max(n_cal, args.cpu_seconds / max(secs / n_cal, 1e-9))))
+        cs, secs, isa = oracle.fast_score_pairs(fs.rows, fs.counts, qs[:n_s], ts[:n_s], op, threads)
+        cpu_dist = int(np.sum(fs.counts[qs[:n_s]].astype(np.int64) * fs.counts[ts[:n_s]].astype(np.int64)))
+        idx = offs[qs[:n_s]].astype(np.int64) + ts[:n_s]          # W == 1: slot == frame position
+        mismatch = int(np.sum(got[idx] != cs))
+        cpu = {"value": cpu_dist / secs, "unit": "distances/s", "cores": threads, "kind": "port",
+               "sample": f"{n_s} random eligible pairs of the same workload ({cpu_dist:.3e} distances, {secs:.1f} s), "
+                         f"oracle tuned path ({isa}, pthreads over pairs)",
+               "gpu_vs_cpu_sample_mismatches": mismatch}
+        if mismatch:
+            print(f"PARITY FAILURE: {mismatch} of {n_s} sampled pairs differ from the CPU oracle", file=sys.stderr)
+
+    if rank == 0:
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # PMC-derived bytes per launch, if collected
+        if os.path.exists(tp):
+            try:
+                t = json.load(open(tp))
+                if t.get("workload") == wl and t.get("n_gpus") == world and t.get("frames") == n_frames:
+                    traffic = t.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        algo_bytes_launch = int(info.algo_bytes)
+        achieved = algo_bytes_launch / (kern_ms * 1e-3) / 1e9
+        kern_rate = local_dist / (kern_ms * 1e-3)
+        out = {
+            "metric": METRIC, "value": value, "unit": "distances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if (args.workload == "auto" or world == 1) else "strong",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": wl_desc, "frames": n_frames, "descriptors_per_frame": n_desc, "min_gap": args.gap,
+                       "pairs_per_step": total_pairs, "distances_per_step": total_dist, "seed": seed,
+                       "sharding": "cyclic by frame" if world > 1 else "none", "kernel_variant": args.variant},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "k_score_rowlane", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "note": "this path is VALU-bound by ~200x (0.016 algorithmic bytes per distance); see roofline_valu"},
+            "roofline_valu": {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
+                              "frac": kern_rate / VALU_PEAK_DIST_PER_S,
+                              "model": "8 v_xor_b32 (2 cyc) + 8 v_bcnt_u32_b32 (4 cyc) per 64 distances per SIMD, "
+                                       "1024 SIMDs @ 2.4 GHz"},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    m.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -217,6 +218,7 @@ int eligible_prefix(const lcm_handle* h, int query_id, int gap) {
 }
 
 int pick_chunk(size_t total_pairs) {
+    if (const char* e = getenv("LCM_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 64) return c; }   // tuning knob
     // enough work items to fill 256 CUs several times over, few enough to amortise the query-frame load
     if (total_pairs >= 65536) return 8;
     if (total_pairs >= 16384) return 4;

@@ -22,6 +22,7 @@
 //   wavefront reduction per query.  Kept for A/B measurement; see DESIGN.md for the numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "lcm_kernels.h"
 
@@ -46,23 +47,48 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // Hamming distance of a VGPR-resident row against a wave-uniform row held in SGPRs:
-// 8 x v_xor_b32 (scalar src0) + one 8-deep v_bcnt_u32_b32 accumulate chain.  The chain is written as inline
-// asm because hipcc -O3 otherwise re-associates the adds into a tree and spends 3 extra v_add3_u32 per distance.
-__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
-    uint32_t d;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
-    return d;
-}
-__device__ __forceinline__ uint32_t bcnt0(uint32_t x) {
-    uint32_t d;
-    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x));
-    return d;
-}
-__device__ __forceinline__ uint32_t ham8(const uint32_t (&q)[8], const uint32_t* s) {
-    uint32_t d = bcnt0(q[0] ^ s[0]);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) d = bcnt_acc(q[k] ^ s[k], d);
-    return d;
+// 8 x v_xor_b32 (scalar src0) + one 8-deep v_bcnt_u32_b32 accumulate chain, in STRICT x,b,x,b program order.
+//   * the chain is inline asm because hipcc -O3 otherwise re-associates the adds into a tree and spends 3 extra
+//     v_add3_u32 per distance;
+//   * the asm is volatile to pin the order: on gfx950 v_xor_b32 issues in ~2 cycles and v_bcnt_u32_b32 in ~4
+//     (profiles/r01_valu_class.txt), and a stream that alternates them one-for-one runs ~15 % faster than the
+//     runs-of-xor / runs-of-bcnt order the compiler's scheduler produces (profiles/r01_loop_order.txt).
+// One query row (8 VGPRs) against TWO train rows (16 SGPRs, rows t and t+1): both distances, both packed keys and the
+// fold into the running minimum, as ONE asm statement so that the instruction order is exactly the one below.
+//
+// Why the `s_nop 0` after every v_xor_b32: measured on gfx950 (profiles/r01_valu_class.txt, r01_order_bench_*.txt),
+// v_xor_b32 is a 2-cycle wave64 instruction and v_bcnt_u32_b32 / v_lshl_or_b32 / v_min3_u32 are 4-cycle ones, but a
+// wave that issues VALU instructions back to back holds the SIMD for 4 cycles per instruction whatever their class:
+// every order of the bare 17.5-instruction mix runs at 73-74 SIMD-cycles per 64 distances (= 17.5 x 4.19).  One
+// non-VALU instruction per (xor, bcnt) pair lets another wave take the slot and the xor then costs 2 cycles:
+// 61-63 cycles per 64 distances, +17 % throughput.  More nops (after both, or s_nop 1) are slower again.
+__device__ __forceinline__ void fold2(uint32_t& best, const uint32_t (&q)[8], const uint32_t* s, uint32_t t0, uint32_t t1) {
+    uint32_t d0, d1, x;
+    asm volatile(
+        "v_xor_b32_e32 %3, %4, %20\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, 0\n\t"
+        "v_xor_b32_e32 %3, %5, %21\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %6, %22\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %7, %23\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %8, %24\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %9, %25\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %10, %26\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %11, %27\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %12, %20\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, 0\n\t"
+        "v_xor_b32_e32 %3, %13, %21\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %14, %22\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %15, %23\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %16, %24\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %17, %25\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %18, %26\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %19, %27\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_lshl_or_b32 %1, %1, 22, %28\n\t"
+        "v_lshl_or_b32 %2, %2, 22, %29\n\t"
+        "v_min3_u32 %0, %0, %1, %2"
+        : "+v"(best), "=&v"(d0), "=&v"(d1), "=&v"(x)
+        : "s"(s[0]), "s"(s[1]), "s"(s[2]), "s"(s[3]), "s"(s[4]), "s"(s[5]), "s"(s[6]), "s"(s[7]),
+          "s"(s[8]), "s"(s[9]), "s"(s[10]), "s"(s[11]), "s"(s[12]), "s"(s[13]), "s"(s[14]), "s"(s[15]),
+          "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]),
+          "s"(t0), "s"(t1));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -120,22 +146,14 @@ __global__ __launch_bounds__(THREADS) void k_score_rowlane(ScoreArgs a) {
                 for (int k = 0; k < 16; ++k) B[k] = T[(t + 2) * 8 + k];
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the VALU block it overlaps
 #pragma unroll
-                for (int j = 0; j < QPT; ++j) {
-                    const uint32_t k0 = (ham8(q[j], A) << KEY_SHIFT) | (uint32_t)t;
-                    const uint32_t k1 = (ham8(q[j], A + 8) << KEY_SHIFT) | (uint32_t)(t + 1);
-                    best[j] = umin3(best[j], k0, k1);
-                }
+                for (int j = 0; j < QPT; ++j) fold2(best[j], q[j], A, (uint32_t)t, (uint32_t)(t + 1));
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): B landed while A was being consumed
 #pragma unroll
                 for (int k = 0; k < 16; ++k) A[k] = T[(t + 4) * 8 + k];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < QPT; ++j) {
-                    const uint32_t k0 = (ham8(q[j], B) << KEY_SHIFT) | (uint32_t)(t + 2);
-                    const uint32_t k1 = (ham8(q[j], B + 8) << KEY_SHIFT) | (uint32_t)(t + 3);
-                    best[j] = umin3(best[j], k0, k1);
-                }
+                for (int j = 0; j < QPT; ++j) fold2(best[j], q[j], B, (uint32_t)(t + 2), (uint32_t)(t + 3));
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // A (rows t+4, t+5) landed while B was being consumed
             }
@@ -182,13 +200,26 @@ __global__ __launch_bounds__(THREADS) void k_score_rowlane(ScoreArgs a) {
     }
 }
 
+// Occupancy throttle: dynamic LDS that the kernel never touches, sized so that exactly `waves_per_simd` workgroups of
+// 256 threads fit a CU's 160 KiB (the measured optimum is an EVEN number of waves per SIMD).
+static unsigned lds_pad_bytes() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* e = getenv("LCM_WAVES_PER_SIMD");      // tuning knob; default below
+        int w = e ? atoi(e) : 4;
+        cached = (w >= 1 && w <= 7) ? (int)((160 * 1024) / w - 512) & ~255 : 0;
+    }
+    return (unsigned)cached;
+}
+
 template <int THREADS, int QPT>
 static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool write_keys, hipStream_t st) {
     if (n_items == 0) return hipSuccess;
+    const unsigned lds = THREADS == 256 ? lds_pad_bytes() : 0;
     if (write_keys)
-        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true>), dim3(n_items), dim3(THREADS), 0, st, a);
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true>), dim3(n_items), dim3(THREADS), lds, st, a);
     else
-        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, false>), dim3(n_items), dim3(THREADS), 0, st, a);
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, false>), dim3(n_items), dim3(THREADS), lds, st, a);
     return hipGetLastError();
 }
 
