@@ -91,11 +91,43 @@ __device__ __forceinline__ void fold2(uint32_t& best, const uint32_t (&q)[8], co
           "s"(t0), "s"(t1));
 }
 
+// Same, but only the minimum DISTANCE is tracked (no train index): what the loop search needs — a LoopCandidate
+// (include/loop_closing.hpp:22-27) carries a match count and a similarity, never a train index, and the match list
+// of a detected loop comes from the pair-mode kernel on demand (README.md:101 "Re-match features on identified loop
+// frames").  Saves the two v_lshl_or_b32 per pair of distances.
+__device__ __forceinline__ void fold2_min(uint32_t& best, const uint32_t (&q)[8], const uint32_t* s) {
+    uint32_t d0, d1, x;
+    asm volatile(
+        "v_xor_b32_e32 %3, %4, %20\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, 0\n\t"
+        "v_xor_b32_e32 %3, %5, %21\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %6, %22\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %7, %23\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %8, %24\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %9, %25\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %10, %26\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %11, %27\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %12, %20\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, 0\n\t"
+        "v_xor_b32_e32 %3, %13, %21\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %14, %22\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %15, %23\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %16, %24\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %17, %25\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %18, %26\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %19, %27\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_min3_u32 %0, %0, %1, %2"
+        : "+v"(best), "=&v"(d0), "=&v"(d1), "=&v"(x)
+        : "s"(s[0]), "s"(s[1]), "s"(s[2]), "s"(s[3]), "s"(s[4]), "s"(s[5]), "s"(s[6]), "s"(s[7]),
+          "s"(s[8]), "s"(s[9]), "s"(s[10]), "s"(s[11]), "s"(s[12]), "s"(s[13]), "s"(s[14]), "s"(s[15]),
+          "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
+}
+
 // ---------------------------------------------------------------------------------------------------
-// Variant 0
+// Variant 0: row-per-lane.  ARGMIN = true tracks (dist, train index) keys; false tracks distances only.
 // ---------------------------------------------------------------------------------------------------
-template <int THREADS, int QPT, bool WRITE_KEYS>
-__global__ __launch_bounds__(THREADS) void k_score_rowlane(ScoreArgs a) {
+template <int THREADS, int QPT, bool ARGMIN, bool WRITE_KEYS>
+__global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
+    static_assert(ARGMIN || !WRITE_KEYS, "keys need the argmin path");
+    constexpr int DSHIFT = ARGMIN ? KEY_SHIFT : 0;      // best[j] >> DSHIFT is the best distance
     constexpr int WAVES = THREADS / 64;
     __shared__ uint32_t red_min[2][WAVES];
     __shared__ uint32_t red_sum[2][WAVES];
@@ -109,15 +141,14 @@ __global__ __launch_bounds__(THREADS) void k_score_rowlane(ScoreArgs a) {
 
     // ---- load this lane's query rows: row = j*THREADS + tid (consecutive lanes -> consecutive 32-byte rows)
     uint32_t q[QPT][8];
-    bool valid[QPT];
+    auto valid = [&](int j) { return j * THREADS + tid < nq; };     // recomputed where needed: keeps VGPRs <= 80
     {
         const uint4* qbase = reinterpret_cast<const uint4*>(a.q_rows + (size_t)it.q_frame * a.q_stride_words);
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
             const int row = j * THREADS + tid;
-            valid[j] = row < nq;
             uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
-            if (valid[j]) { lo = qbase[row * 2]; hi = qbase[row * 2 + 1]; }
+            if (row < nq) { lo = qbase[row * 2]; hi = qbase[row * 2 + 1]; }
             q[j][0] = lo.x; q[j][1] = lo.y; q[j][2] = lo.z; q[j][3] = lo.w;
             q[j][4] = hi.x; q[j][5] = hi.y; q[j][6] = hi.z; q[j][7] = hi.w;
         }
@@ -146,14 +177,18 @@ __global__ __launch_bounds__(THREADS) void k_score_rowlane(ScoreArgs a) {
                 for (int k = 0; k < 16; ++k) B[k] = T[(t + 2) * 8 + k];
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the VALU block it overlaps
 #pragma unroll
-                for (int j = 0; j < QPT; ++j) fold2(best[j], q[j], A, (uint32_t)t, (uint32_t)(t + 1));
+                for (int j = 0; j < QPT; ++j) {
+                    if (ARGMIN) fold2(best[j], q[j], A, (uint32_t)t, (uint32_t)(t + 1)); else fold2_min(best[j], q[j], A);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): B landed while A was being consumed
 #pragma unroll
                 for (int k = 0; k < 16; ++k) A[k] = T[(t + 4) * 8 + k];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < QPT; ++j) fold2(best[j], q[j], B, (uint32_t)(t + 2), (uint32_t)(t + 3));
+                for (int j = 0; j < QPT; ++j) {
+                    if (ARGMIN) fold2(best[j], q[j], B, (uint32_t)(t + 2), (uint32_t)(t + 3)); else fold2_min(best[j], q[j], B);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // A (rows t+4, t+5) landed while B was being consumed
             }
@@ -164,11 +199,11 @@ __global__ __launch_bounds__(THREADS) void k_score_rowlane(ScoreArgs a) {
         if (WRITE_KEYS) {
 #pragma unroll
             for (int j = 0; j < QPT; ++j)
-                if (valid[j]) a.keys[out * a.keys_stride + j * THREADS + tid] = best[j];
+                if (valid(j)) a.keys[out * a.keys_stride + j * THREADS + tid] = best[j];
         }
         uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) if (valid[j]) dmin = min(dmin, best[j] >> KEY_SHIFT);
+        for (int j = 0; j < QPT; ++j) if (valid(j)) dmin = min(dmin, best[j] >> DSHIFT);
         dmin = wave_min(dmin);
         const int par = s & 1;
         if (WAVES > 1) {
@@ -181,7 +216,7 @@ __global__ __launch_bounds__(THREADS) void k_score_rowlane(ScoreArgs a) {
         thr = max(thr, (uint32_t)a.dist_floor);
         uint32_t cnt = 0;
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) cnt += (valid[j] && (best[j] >> KEY_SHIFT) <= thr) ? 1u : 0u;
+        for (int j = 0; j < QPT; ++j) cnt += (valid(j) && (best[j] >> DSHIFT) <= thr) ? 1u : 0u;
         cnt = wave_sum(cnt);
         if (WAVES > 1) {
             if (lane == 0) red_sum[par][wave] = cnt;
@@ -201,35 +236,39 @@ __global__ __launch_bounds__(THREADS) void k_score_rowlane(ScoreArgs a) {
 }
 
 // Occupancy throttle: dynamic LDS that the kernel never touches, sized so that exactly `waves_per_simd` workgroups of
-// 256 threads fit a CU's 160 KiB (the measured optimum is an EVEN number of waves per SIMD).
+// 256 threads fit a CU's 160 KiB (6 is the measured optimum; the register budget is 80 VGPRs).
 static unsigned lds_pad_bytes() {
     static int cached = -1;
     if (cached < 0) {
         const char* e = getenv("LCM_WAVES_PER_SIMD");      // tuning knob; default below
-        int w = e ? atoi(e) : 4;
+        int w = e ? atoi(e) : 6;
         cached = (w >= 1 && w <= 7) ? (int)((160 * 1024) / w - 512) & ~255 : 0;
     }
     return (unsigned)cached;
 }
 
 template <int THREADS, int QPT>
-static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool write_keys, hipStream_t st) {
+static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool write_keys, bool argmin, hipStream_t st) {
     if (n_items == 0) return hipSuccess;
     const unsigned lds = THREADS == 256 ? lds_pad_bytes() : 0;
     if (write_keys)
-        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true>), dim3(n_items), dim3(THREADS), lds, st, a);
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true, true>), dim3(n_items), dim3(THREADS), lds, st, a);
+    else if (argmin)
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true, false>), dim3(n_items), dim3(THREADS), lds, st, a);
     else
-        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, false>), dim3(n_items), dim3(THREADS), lds, st, a);
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, false, false>), dim3(n_items), dim3(THREADS), lds, st, a);
     return hipGetLastError();
 }
 
+// variant 0: bulk scoring tracks distances only (default); variant 1: bulk scoring tracks full (dist, idx) keys too
+// (the kernel the pair mode always uses) — kept selectable so both can be measured on the same workload.
 hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
                         hipStream_t st) {
-    (void)variant;
-    if (max_query_rows <= 512) return launch_rowlane<64, 8>(a, n_items, write_keys, st);
-    if (max_query_rows <= 1024) return launch_rowlane<128, 8>(a, n_items, write_keys, st);
-    if (max_query_rows <= 1536) return launch_rowlane<192, 8>(a, n_items, write_keys, st);
-    if (max_query_rows <= 2048) return launch_rowlane<256, 8>(a, n_items, write_keys, st);
+    const bool argmin = write_keys || variant == 1;
+    if (max_query_rows <= 512) return launch_rowlane<64, 8>(a, n_items, write_keys, argmin, st);
+    if (max_query_rows <= 1024) return launch_rowlane<128, 8>(a, n_items, write_keys, argmin, st);
+    if (max_query_rows <= 1536) return launch_rowlane<192, 8>(a, n_items, write_keys, argmin, st);
+    if (max_query_rows <= 2048) return launch_rowlane<256, 8>(a, n_items, write_keys, argmin, st);
     return hipErrorInvalidValue;
 }
 
