@@ -42,6 +42,18 @@ WORKLOADS = {
 }
 
 
+def host_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,7 +65,8 @@ def main():
     ap.add_argument("--gap", type=int, default=30)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (A/B measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget; 0 disables")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores this process may use")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU rehearsal of the N > 1 path)")
     args = ap.parse_args()
 
     import torch  # first: the process then has ONE HIP runtime (torch's), which liblcm_hip.so binds to
@@ -71,11 +84,16 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the matcher has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()          # rehearsal: ranks may share a card
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- workload ------------------------------------------------------------------------------------
     wl = args.workload
@@ -116,14 +134,15 @@ def main():
                       q_stride_rows=fs.stride_rows)
         n_local, offs = m.all_vs_all_plan(**q_args)
     scores = torch.zeros(max(n_local, 1), dtype=torch.int64, device=dev)     # 8-byte lcm_score records
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        n_t = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        n_t = torch.tensor([n_local], dtype=torch.int64, device=cdev)
         lens = [torch.zeros_like(n_t) for _ in range(world)]
         dist.all_gather(lens, n_t)
         lens = [int(x.item()) for x in lens]
         cap = max(lens)
         send = torch.zeros(cap, dtype=torch.int64, device=dev)
-        recv = torch.empty(world * cap, dtype=torch.int64, device=dev)
+        recv = torch.empty(world * cap, dtype=torch.int64, device=cdev)
     else:
         lens = [n_local]
 
@@ -132,7 +151,10 @@ def main():
             m.all_vs_all(scores.data_ptr(), n_local, **q_args)
         else:
             m.all_vs_all(send.data_ptr(), cap, **q_args)          # kernel writes straight into the send buffer
-            dist.all_gather_into_tensor(recv, send)               # RCCL over xGMI: per-shard score records
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(recv, send)           # RCCL over xGMI: per-shard score records
+            else:
+                dist.all_gather(list(recv.view(world, cap).unbind(0)), send.cpu())
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -150,7 +172,7 @@ def main():
         # (reading the previous launch's HIP events would sync; collect after the timed region instead)
     barrier()
     t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
@@ -164,7 +186,20 @@ def main():
     kern_ms = float(np.mean(kernel_ms))
 
     local_dist = int(info.distances)
-    tot = torch.tensor([local_dist, int(info.pairs), int(info.algo_bytes)], dtype=torch.int64, device=dev)
+    # the same workload through the (dist, idx)-key kernel the pair mode uses: reported beside the headline number
+    argmin_ms = None
+    if args.variant == 0:
+        m.set_kernel_variant(1)
+        ms = []
+        for _ in range(2):
+            m.all_vs_all((send if world > 1 else scores).data_ptr(), cap if world > 1 else n_local, **q_args)
+            ms.append(m.launch_info().kernel_ms)
+        argmin_ms = float(np.mean(ms))
+        m.set_kernel_variant(0)
+        m.all_vs_all((send if world > 1 else scores).data_ptr(), cap if world > 1 else n_local, **q_args)
+        m.sync()
+
+    tot = torch.tensor([local_dist, int(info.pairs), int(info.algo_bytes)], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     total_dist, total_pairs, total_bytes = (int(x) for x in tot.tolist())
@@ -175,12 +210,12 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         oracle = entry.load_oracle()
         oracle.build()
-        threads = args.cpu_threads or (os.cpu_count() or 1)
+        threads = args.cpu_threads or host_cores()
         rng = np.random.default_rng(123)
         got = np.zeros(n_local, pkg.capi.SCORE_DTYPE)
         torch.cuda.synchronize(dev)
         got[:] = scores.cpu().numpy().view(pkg.capi.SCORE_DTYPE)[:n_local]
-        qs = rng.integers(args.gap, n_frames, size=4096)
+        qs = rng.integers(args.gap, n_frames, size=262144)
         ts = np.array([rng.integers(0, q - args.gap + 1) for q in qs])
         op = oracle.default_params(min_gap=args.gap)
         # calibrate on a few pairs, then size the sample for ~cpu_seconds of CPU work
@@ -227,6 +262,10 @@ def main():
                               "frac": kern_rate / VALU_PEAK_DIST_PER_S,
                               "model": "8 v_xor_b32 (2 cyc) + 8 v_bcnt_u32_b32 (4 cyc) per 64 distances per SIMD, "
                                        "1024 SIMDs @ 2.4 GHz"},
+            "argmin_kernel": None if argmin_ms is None else {
+                "what": "same workload, kernel variant that also tracks the train index of every minimum "
+                        "(the (dist, idx)-key kernel behind lcm_match_pair / matchFeatures)",
+                "kernel_ms": argmin_ms, "distances_per_s": local_dist / (argmin_ms * 1e-3)},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

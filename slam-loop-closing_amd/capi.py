@@ -308,3 +308,78 @@ class Matcher:
     def dev_download(self, d_ptr: int, out: np.ndarray):
         assert out.flags["C_CONTIGUOUS"]
         _check(self._lib.lcm_dev_download(self._h, out.ctypes.data_as(_vp), _vp(d_ptr), out.nbytes))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# include/lcm_host.h: the C shim over the C++ host class loop_closing::LoopClosingSystem
+# ---------------------------------------------------------------------------------------------------------
+_HOST_SIGNATURES = {
+    "lcs_create": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lcs_destroy": (None, [_vp]),
+    "lcs_process_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "lcs_match_features": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
+    "lcs_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i32p]),
+    "lcs_num_frames": (C.c_int, [_vp]),
+    "lcs_num_loop_closures": (C.c_int, [_vp]),
+    "lcs_get_loop_closures": (C.c_int, [_vp, _vp, C.c_int, _i32p]),
+    "lcs_save_results": (C.c_int, [_vp, C.c_char_p]),
+}
+
+
+class LoopClosingSystem:
+    """Python handle on the C++ loop_closing::LoopClosingSystem (csrc/loop_closing_system.hpp) — same method names as
+    the reference class (include/loop_closing.hpp:29-80), driven through the C shim."""
+
+    def __init__(self, loop_threshold: float = 0.7, min_loop_gap: int = 30, device: int = 0, shard_rank: int = 0,
+                 shard_world: int = 1):
+        self._lib = load_library()
+        for name, (res, args) in _HOST_SIGNATURES.items():
+            fn = getattr(self._lib, name)
+            fn.restype, fn.argtypes = res, args
+        self._s = _vp()
+        _check(self._lib.lcs_create(loop_threshold, min_loop_gap, device, shard_rank, shard_world, C.byref(self._s)))
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._lib.lcs_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _hcheck(self, rc):
+        if rc != 0:
+            raise LcmError(rc, self._lib.lcm_last_error().decode("utf-8", "replace"))
+
+    def processFrame(self, descriptors, frame_id: int, num_keypoints: int = -1):
+        d = _rows(descriptors)
+        self._hcheck(self._lib.lcs_process_frame(self._s, _ptr(d), d.shape[0], num_keypoints, frame_id))
+
+    def matchFeatures(self, frame1_id: int, frame2_id: int, cap: int = 65536) -> np.ndarray:
+        out = np.zeros(cap, DMATCH_DTYPE)
+        n = C.c_int32(0)
+        self._hcheck(self._lib.lcs_match_features(self._s, frame1_id, frame2_id, out.ctypes.data_as(_vp), cap, C.byref(n)))
+        return out[: n.value]
+
+    def detectLoops(self, current_frame_id: int) -> np.ndarray:
+        cap = max(self._lib.lcs_num_frames(self._s), 1)
+        out = np.zeros(cap, CANDIDATE_DTYPE)
+        n = C.c_int32(0)
+        self._hcheck(self._lib.lcs_detect_loops(self._s, current_frame_id, out.ctypes.data_as(_vp), cap, C.byref(n)))
+        return out[: n.value]
+
+    def getLoopClosures(self) -> np.ndarray:
+        cap = max(self._lib.lcs_num_loop_closures(self._s), 1)
+        out = np.zeros(cap, CANDIDATE_DTYPE)
+        n = C.c_int32(0)
+        self._hcheck(self._lib.lcs_get_loop_closures(self._s, out.ctypes.data_as(_vp), cap, C.byref(n)))
+        return out[: n.value]
+
+    def numFrames(self) -> int:
+        return self._lib.lcs_num_frames(self._s)
+
+    def saveResults(self, output_dir: str):
+        self._hcheck(self._lib.lcs_save_results(self._s, output_dir.encode()))

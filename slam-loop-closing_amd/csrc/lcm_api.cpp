@@ -69,6 +69,10 @@ struct Plan {            // cached work list of one bulk call shape
 
 }  // namespace
 
+namespace lcm {
+void set_last_error(const char* msg) { g_err = msg ? msg : ""; }   // for the host-class shim (lcs_host.cpp)
+}
+
 struct lcm_handle {
     lcm_params params;
     int device = 0;

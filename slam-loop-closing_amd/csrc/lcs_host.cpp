@@ -108,19 +108,20 @@ void LoopClosingSystem::saveResults(const std::string& output_dir) {
 // ---------------------------------------------------------------------------------------------------------
 struct lcs_system {
     loop_closing::LoopClosingSystem sys;
-    std::string err;
     lcs_system(double thr, int gap, int dev, int r, int w) : sys(thr, gap, dev, r, w) {}
 };
 
+namespace lcm { void set_last_error(const char* msg); }
+
 namespace {
-thread_local std::string g_host_err;
+// exceptions never cross the C boundary: they become a status + the lcm_last_error() message
 template <typename F>
 int guarded(F&& f) {
     try { f(); return LCM_OK; }
-    catch (const std::invalid_argument& e) { g_host_err = e.what(); return LCM_ERR_INVALID_ARG; }
-    catch (const std::out_of_range& e) { g_host_err = e.what(); return LCM_ERR_NOT_FOUND; }
-    catch (const std::bad_alloc&) { g_host_err = "out of memory"; return LCM_ERR_OOM; }
-    catch (const std::exception& e) { g_host_err = e.what(); return LCM_ERR_HIP; }
+    catch (const std::invalid_argument& e) { lcm::set_last_error(e.what()); return LCM_ERR_INVALID_ARG; }
+    catch (const std::out_of_range& e) { lcm::set_last_error(e.what()); return LCM_ERR_NOT_FOUND; }
+    catch (const std::bad_alloc&) { lcm::set_last_error("out of memory"); return LCM_ERR_OOM; }
+    catch (const std::exception& e) { lcm::set_last_error(e.what()); return LCM_ERR_HIP; }
 }
 }  // namespace
 

@@ -1,0 +1,80 @@
+"""The C-ABI library loads and exports exactly what include/*.h declares (no compute calls: there is no GPU here),
+and refuses to work without a device instead of falling back to a CPU path."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"LCM_API\s+[\w\s\*]+?\b(l(?:cm|cs)_\w+)\s*\(", txt)))
+
+
+def test_headers_declare_something():
+    assert len(declared("lcm.h")) >= 25
+    assert len(declared("lcm_host.h")) >= 8
+
+
+@pytest.mark.parametrize("header", ["lcm.h", "lcm_host.h"])
+def test_library_exports_every_declared_symbol(pkg, header):
+    lib = ctypes.CDLL(pkg.capi.LIB_PATH)
+    for name in declared(header):
+        assert hasattr(lib, name), f"{name} declared in include/{header} but not exported"
+
+
+def test_ctypes_binding_covers_lcm_h(pkg):
+    assert sorted(pkg.capi._SIGNATURES) == declared("lcm.h")
+
+
+def test_struct_layouts_match_reference_types(pkg):
+    c = pkg.capi
+    # LoopCandidate: int, int, int, (pad), double — include/loop_closing.hpp:22-27
+    assert ctypes.sizeof(c.LoopCandidate) == 24 and c.LoopCandidate.similarity_score.offset == 16
+    # cv::DMatch: int queryIdx, trainIdx, imgIdx; float distance
+    assert ctypes.sizeof(c.DMatch) == 16 and c.DMatch.distance.offset == 12
+    assert ctypes.sizeof(c.Score) == 8
+    p = c.default_params()
+    assert (p.ratio, p.dist_floor, p.min_matches, p.min_gap, p.sim_threshold) == (2, 0, 50, 30, 0.15)
+
+
+def test_backend_name_and_loop_test_need_no_device(pkg):
+    lib = pkg.load_library()
+    assert lib.lcm_backend_name() == b"hip-gfx950"
+    p = pkg.default_params()
+    sim = ctypes.c_double()
+    s = pkg.capi.Score(300, 3, 2000)
+    assert lib.lcm_loop_test(ctypes.byref(p), ctypes.byref(s), 2000, 2000, ctypes.byref(sim)) == 0 and sim.value == 0.15
+    s = pkg.capi.Score(301, 3, 2000)
+    assert lib.lcm_loop_test(ctypes.byref(p), ctypes.byref(s), 2000, 2000, ctypes.byref(sim)) == 1
+    s = pkg.capi.Score(49, 3, 60)
+    assert lib.lcm_loop_test(ctypes.byref(p), ctypes.byref(s), 60, 60, ctypes.byref(sim)) == 0     # < 50 matches
+    assert lib.lcm_loop_test(ctypes.byref(p), ctypes.byref(s), 0, 60, ctypes.byref(sim)) == 0 and sim.value == 0.0
+
+
+def test_no_cpu_fallback_without_a_device(pkg):
+    lib = pkg.load_library()
+    if lib.lcm_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(pkg.LcmError) as e:
+        pkg.Matcher()
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)        # LCM_ERR_NO_DEVICE
+    h = ctypes.c_void_p()
+    rc = lib.lcs_create(ctypes.c_double(0.15), 30, 0, 0, 1, ctypes.byref(h))
+    assert rc == -2 and not h.value
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg_dir = os.path.join(ROOT, "slam-loop-closing_amd")
+    for d, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                txt = open(os.path.join(d, f), errors="replace").read()
+                assert "lcm_oracle" not in txt and "oracle/" not in txt.replace("oracle/ is", "").replace("under oracle/", ""), \
+                    f"{f} refers to the oracle"

@@ -1,0 +1,138 @@
+"""BASELINE.json's full sizes (2000-row frames, 1000-frame database): size-independent properties of the domain
+plus sampled oracle checks, since the scalar oracle cannot score 470,935 full-size pairs in test time."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(rng, n):
+    return rng.integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+def ham(a, b):
+    return np.unpackbits(a ^ b, axis=-1).sum(axis=-1)
+
+
+def test_self_match_is_identity_up_to_duplicates(matcher):
+    rng = np.random.default_rng(1)
+    a = rnd(rng, 2000)
+    a[1500] = a[20]                                   # a duplicate: row 1500 must report index 20, not itself
+    idx, d = matcher.match_pair(a, a)
+    assert (d == 0).all()
+    want = np.arange(2000); want[1500] = 20
+    np.testing.assert_array_equal(idx, want)
+
+
+def test_reported_distance_is_distance_to_reported_row(matcher):
+    rng = np.random.default_rng(2)
+    q, t = rnd(rng, 2000), rnd(rng, 2000)
+    idx, d = matcher.match_pair(q, t)
+    np.testing.assert_array_equal(ham(q, t[idx]), d)
+    # and no row sampled at random beats it; ties must not have a lower index
+    for _ in range(20):
+        j = rng.integers(0, 2000, 2000)
+        dj = ham(q, t[j])
+        assert (dj >= d).all()
+        assert ((dj > d) | (j >= idx)).all()
+
+
+def test_concatenation_and_monotonicity(matcher):
+    """best over [T1; T2] == lexicographic min of (best over T1) and (best over T2, index shifted)."""
+    rng = np.random.default_rng(3)
+    q, t1, t2 = rnd(rng, 2000), rnd(rng, 1203), rnd(rng, 797)
+    t2[5] = t1[7]                                     # tie across the seam: T1's copy must win
+    q[0] = t1[7]
+    i1, d1 = matcher.match_pair(q, t1)
+    i2, d2 = matcher.match_pair(q, t2)
+    i12, d12 = matcher.match_pair(q, np.concatenate([t1, t2]))
+    take2 = d2 < d1                                   # strict: ties go to the earlier block
+    np.testing.assert_array_equal(d12, np.where(take2, d2, d1))
+    np.testing.assert_array_equal(i12, np.where(take2, i2 + len(t1), i1))
+    assert i12[0] == 7 and d12[0] == 0
+    assert (d12 <= d1).all()                          # more train rows can only lower the best distance
+
+
+def test_train_permutation_invariance(matcher):
+    rng = np.random.default_rng(4)
+    q, t = rnd(rng, 1999), rnd(rng, 1777)
+    perm = rng.permutation(len(t))
+    i0, d0 = matcher.match_pair(q, t)
+    i1, d1 = matcher.match_pair(q, t[perm])
+    np.testing.assert_array_equal(d0, d1)
+    # uniform random rows: minima are unique with overwhelming probability wherever the rows differ
+    np.testing.assert_array_equal(perm[i1], i0)
+
+
+def test_query_order_equivariance_and_chunking(matcher):
+    """Queries are independent: any subset / order gives the same per-row answers (also across the 2048-row
+    chunk boundary of the pair kernel)."""
+    rng = np.random.default_rng(5)
+    q, t = rnd(rng, 5000), rnd(rng, 900)
+    i0, d0 = matcher.match_pair(q, t)
+    perm = rng.permutation(len(q))
+    i1, d1 = matcher.match_pair(q[perm], t)
+    np.testing.assert_array_equal(i1, i0[perm])
+    np.testing.assert_array_equal(d1, d0[perm])
+    i2, d2 = matcher.match_pair(q[2040:2060], t)
+    np.testing.assert_array_equal(i2, i0[2040:2060])
+
+
+def test_cfg2_full_database_sampled_vs_oracle_and_sharded(matcher, oracle, pkg):
+    """configs[1]: 1000 frames x 2000 descriptors, min_gap 30 — all 470,935 pairs on the GPU; 200 random pairs checked
+    against the oracle's tuned CPU path (itself checked against the scalar oracle in test_oracle_numpy.py) and 3
+    against the scalar oracle; the 4-way cyclic-sharded run must merge to the byte-identical array (K10); both kernel
+    variants (distance-only / full keys) must agree."""
+    import torch  # noqa: F401  (only to fail early if the image is broken)
+    fs = pkg.synth.make_frames(1000, 2000, seed=pkg.synth.BASE_SEED + 2)
+    gap = 30
+    matcher.set_params(min_gap=gap)
+    d_rows = matcher.dev_alloc(fs.rows.nbytes)
+    d_counts = matcher.dev_alloc(fs.counts.nbytes)
+    try:
+        matcher.dev_upload(d_rows, fs.rows)
+        matcher.dev_upload(d_counts, fs.counts)
+
+        def run(positions, external):
+            matcher.clear()
+            fb = fs.stride_rows * 32
+            for f in positions:
+                matcher.append_device(int(fs.ids[f]), d_rows + int(f) * fb, int(fs.counts[f]))
+            kw = dict(d_query_rows=d_rows, d_query_counts=d_counts, q_ids=fs.ids, q_stride_rows=fs.stride_rows) if external else {}
+            n, offs = matcher.all_vs_all_plan(**kw)
+            d = matcher.dev_alloc(max(n, 1) * 8)
+            matcher.all_vs_all(d, n, **kw)
+            out = np.zeros(n, pkg.capi.SCORE_DTYPE)
+            matcher.sync()
+            matcher.dev_download(d, out)
+            matcher.dev_free(d)
+            return out, offs
+
+        full, offs = run(range(1000), False)
+        assert len(full) == 470935 == pkg.synth.n_pairs_all_vs_all(1000, gap)
+        info = matcher.launch_info()
+        assert info.distances == 470935 * 2000 * 2000
+        assert (full["n_train"] == 2000).all() and (full["good_count"] <= 2000).all() and (full["good_count"] >= 1).all()
+
+        matcher.set_kernel_variant(1)
+        keyed, _ = run(range(1000), False)
+        matcher.set_kernel_variant(0)
+        np.testing.assert_array_equal(keyed, full)
+
+        rng = np.random.default_rng(7)
+        qs = rng.integers(gap, 1000, 200)
+        ts = np.array([rng.integers(0, q - gap + 1) for q in qs])
+        p = oracle.default_params(min_gap=gap)
+        cpu, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, qs, ts, p, n_threads=8)
+        np.testing.assert_array_equal(full[offs[qs].astype(np.int64) + ts], cpu)
+        for q, t in zip(qs[:3], ts[:3]):
+            assert full[int(offs[q]) + int(t)] == oracle.pair_score(fs.frame(q), fs.frame(t), p)
+
+        shards = [run(pkg.sharding.owned_positions(1000, r, 4), True)[0] for r in range(4)]
+        merged, moffs = pkg.sharding.merge_shard_scores(shards, fs.ids, gap)
+        np.testing.assert_array_equal(merged, full)
+        np.testing.assert_array_equal(moffs, offs.astype(np.int64))
+    finally:
+        matcher.dev_free(d_rows); matcher.dev_free(d_counts)
+        matcher.set_params(min_gap=30)
+        matcher.clear()

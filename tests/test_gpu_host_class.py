@@ -1,0 +1,89 @@
+"""The C++ host mirror of loop_closing::LoopClosingSystem (csrc/loop_closing_system.hpp), driven through its C shim:
+processFrame / matchFeatures / detectLoops / getLoopClosures / saveResults vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_process_frames_online_equals_oracle(pkg, oracle, tmp_path):
+    fs = pkg.synth.make_frames(40, 400, seed=3, ragged=True, dup_frac=0.3)
+    gap, thr = 6, 0.15
+    sys_ = pkg.LoopClosingSystem(thr, gap)
+    try:
+        for f in range(fs.n_frames):
+            sys_.processFrame(fs.frame(f), int(fs.ids[f]))
+        assert sys_.numFrames() == fs.n_frames
+        p = oracle.default_params(min_gap=gap, sim_threshold=thr)
+        want = np.concatenate([oracle.detect_loops(fs.rows, fs.counts, fs.ids, c, p) for c in range(fs.n_frames)])
+        got = sys_.getLoopClosures()
+        assert len(want) > 0
+        for f in ("current_frame_id", "matched_frame_id", "num_matches", "similarity_score"):
+            np.testing.assert_array_equal(got[f], want[f])
+        # detectLoops on a stored frame == what processFrame recorded for it
+        c = int(want["current_frame_id"][0])
+        one = sys_.detectLoops(c)
+        np.testing.assert_array_equal(one["matched_frame_id"], want["matched_frame_id"][want["current_frame_id"] == c])
+        # matchFeatures(frame1, frame2) on two stored frames
+        a, b = int(want["current_frame_id"][0]), int(want["matched_frame_id"][0])
+        m = sys_.matchFeatures(a, b)
+        om, _ = oracle.match_features(fs.frame(a), fs.frame(b), p)     # ids == positions here
+        for f in ("query_idx", "train_idx", "img_idx", "distance"):
+            np.testing.assert_array_equal(m[f], om[f])
+        assert len(m) == int(want["num_matches"][0])
+        # saveResults: README.md:142-165 text format
+        out = tmp_path / "loop_closing_results"
+        sys_.saveResults(str(out))
+        txt = (out / "loop_closures.txt").read_text()
+        assert f"Total frames processed: {fs.n_frames}" in txt
+        assert f"Loop closures detected: {len(want)}" in txt
+        first = want[0]
+        assert f"Frame {first['current_frame_id']} <-> Frame {first['matched_frame_id']}\n  Matches: {first['num_matches']}\n  Similarity: " in txt
+        assert txt.count(" <-> ") == len(want)
+    finally:
+        sys_.close()
+
+
+def test_header_default_threshold_and_errors(pkg, oracle):
+    fs = pkg.synth.make_frames(36, 300, seed=8)
+    sys_ = pkg.LoopClosingSystem()                     # header defaults: 0.7 / 30 (include/loop_closing.hpp:31)
+    try:
+        for f in range(fs.n_frames):
+            sys_.processFrame(fs.frame(f), int(fs.ids[f]))
+        p = oracle.default_params(min_gap=30, sim_threshold=0.7)
+        want = np.concatenate([oracle.detect_loops(fs.rows, fs.counts, fs.ids, c, p) for c in range(fs.n_frames)])
+        got = sys_.getLoopClosures()
+        np.testing.assert_array_equal(got["matched_frame_id"], want["matched_frame_id"])
+        np.testing.assert_array_equal(got["similarity_score"], want["similarity_score"])
+        with pytest.raises(pkg.LcmError):
+            sys_.processFrame(fs.frame(0), 3)          # ids must increase
+        with pytest.raises(pkg.LcmError):
+            sys_.detectLoops(9999)
+    finally:
+        sys_.close()
+
+
+def test_sharded_host_objects_partition_the_candidates(pkg, oracle):
+    """Two LoopClosingSystem objects with shard_world = 2 on the one GPU: their candidates merge to the full set."""
+    fs = pkg.synth.make_frames(30, 300, seed=5, dup_frac=0.3)
+    gap = 4
+    shards = [pkg.LoopClosingSystem(0.15, gap, 0, r, 2) for r in range(2)]
+    try:
+        for f in range(fs.n_frames):
+            for s in shards:
+                s.processFrame(fs.frame(f), int(fs.ids[f]))
+        p = oracle.default_params(min_gap=gap)
+        want = np.concatenate([oracle.detect_loops(fs.rows, fs.counts, fs.ids, c, p) for c in range(fs.n_frames)])
+        got = np.concatenate([s.getLoopClosures() for s in shards])
+        order = np.lexsort((got["matched_frame_id"], got["current_frame_id"]))
+        got = got[order]
+        assert len(want) > 0
+        for f in ("current_frame_id", "matched_frame_id", "num_matches", "similarity_score"):
+            np.testing.assert_array_equal(got[f], want[f])
+        for r, s in enumerate(shards):
+            assert all(int(mid) % 2 == r for mid in s.getLoopClosures()["matched_frame_id"])
+    finally:
+        for s in shards:
+            s.close()

@@ -1,0 +1,73 @@
+"""N > 1 host logic on CPU: world_size-2 gloo processes, each scoring its cyclic shard (the CPU oracle stands in for
+the HIP scorer — this test covers ownership, offsets, the all-gather of variable-length score arrays and the merge,
+not the kernel)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import load_oracle, load_package
+
+    pkg, orc = load_package(), load_oracle()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gap = 3
+        fs = pkg.synth.make_frames(23, 48, seed=99, ragged=True, dup_frac=0.4)
+        fs.counts[5] = 0
+        p = orc.default_params(min_gap=gap)
+        # this rank's shard scores, in (query asc, owned stored asc) order — what lcm_all_vs_all writes on a GPU rank
+        local, _ = orc.all_vs_all(fs.rows, fs.counts, fs.ids, p, rank, world)
+        expect_n = int(pkg.sharding.shard_eligible_counts(fs.ids, gap, rank, world).sum())
+        assert len(local) == expect_n
+        t = torch.from_numpy(local.view(np.int64).copy()) if len(local) else torch.zeros(0, dtype=torch.int64)
+        shards = pkg.sharding.all_gather_scores(t, len(local))
+        merged, offs = pkg.sharding.merge_shard_scores(shards, fs.ids, gap)
+        full, foffs = orc.all_vs_all(fs.rows, fs.counts, fs.ids, p)
+        assert np.array_equal(merged, full)
+        assert np.array_equal(offs, foffs.astype(np.int64))
+        np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array([len(merged)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_sharded_merge_equals_single(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    vals = [int(np.load(tmp_path / f"ok{r}.npy")[0]) for r in range(world)]
+    assert len(set(vals)) == 1 and vals[0] > 0
+
+
+def test_ownership_and_offsets(pkg):
+    sh = pkg.sharding
+    ids = np.arange(0, 50, 2)                       # ids 0,2,...,48 ; gap 7 -> id difference >= 7
+    e = sh.eligible_counts(ids, 7)
+    assert e.tolist() == [int(np.sum(ids[c] - ids >= 7)) for c in range(len(ids))]
+    for world in (1, 2, 3, 8):
+        tot = np.zeros_like(e)
+        for r in range(world):
+            er = sh.shard_eligible_counts(ids, 7, r, world)
+            assert er.tolist() == [int(np.sum((ids[c] - ids >= 7) & (np.arange(len(ids)) % world == r))) for c in range(len(ids))]
+            tot += er
+            assert sh.owned_positions(len(ids), r, world).tolist() == list(range(r, len(ids), world))
+        assert tot.tolist() == e.tolist()
+    assert sh.eligible_counts(ids, 0).tolist() == list(range(len(ids)))      # gap 0 still never pairs a frame with itself
