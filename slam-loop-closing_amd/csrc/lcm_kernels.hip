@@ -15,7 +15,8 @@
 //     in the inner loop;
 //   * per-query running minimum is a packed key (dist << 22 | train_idx) folded with v_min3_u32, so the lowest
 //     train index wins ties for free (strict-'<' scan order of OpenCV's batchDistance);
-//   * per pair, the min-of-mins and the good-match count are wavefront shuffle reductions + a 4-entry LDS combine.
+//   * per pair, the min-of-mins and the good-match count are LDS-atomic reductions (ds_min_u32 / ds_add_u32) over
+//     the workgroup's lanes.
 //
 // Variant 1 — "train-row-per-lane, queries staged in LDS" (the mapping BASELINE.json's north_star sketches):
 //   lanes own train rows (coalesced loads), query rows are broadcast from LDS, per-query min/argmin is a
@@ -35,24 +36,6 @@ __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
     return min(min(a, b), c);   // v_min3_u32
 }
 
-__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    return v;
-}
-
-// Hamming distance of a VGPR-resident row against a wave-uniform row held in SGPRs:
-// 8 x v_xor_b32 (scalar src0) + one 8-deep v_bcnt_u32_b32 accumulate chain, in STRICT x,b,x,b program order.
-//   * the chain is inline asm because hipcc -O3 otherwise re-associates the adds into a tree and spends 3 extra
-//     v_add3_u32 per distance;
-//   * the asm is volatile to pin the order: on gfx950 v_xor_b32 issues in ~2 cycles and v_bcnt_u32_b32 in ~4
-//     (profiles/r01_valu_class.txt), and a stream that alternates them one-for-one runs ~15 % faster than the
-//     runs-of-xor / runs-of-bcnt order the compiler's scheduler produces (profiles/r01_loop_order.txt).
 // One query row (8 VGPRs) against TWO train rows (16 SGPRs, rows t and t+1): both distances, both packed keys and the
 // fold into the running minimum, as ONE asm statement so that the instruction order is exactly the one below.
 //
@@ -128,13 +111,12 @@ template <int THREADS, int QPT, bool ARGMIN, bool WRITE_KEYS>
 __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
     static_assert(ARGMIN || !WRITE_KEYS, "keys need the argmin path");
     constexpr int DSHIFT = ARGMIN ? KEY_SHIFT : 0;      // best[j] >> DSHIFT is the best distance
-    constexpr int WAVES = THREADS / 64;
-    __shared__ uint32_t red_min[2][WAVES];
-    __shared__ uint32_t red_sum[2][WAVES];
+    __shared__ uint32_t red_min[2];
+    __shared__ uint32_t red_sum[2];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) { red_min[0] = red_min[1] = 0xFFFFFFFFu; red_sum[0] = red_sum[1] = 0u; }
+    __syncthreads();
 
     const WorkItem it = a.items[blockIdx.x];
     const int nq = a.q_counts[it.q_frame];
@@ -201,30 +183,25 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
             for (int j = 0; j < QPT; ++j)
                 if (valid(j)) a.keys[out * a.keys_stride + j * THREADS + tid] = best[j];
         }
+        // min-of-mins and good-match count: per-lane partials folded with LDS atomics (ds_min_u32 / ds_add_u32), one
+        // word per pair parity.  Deliberately not a shuffle tree: this runs once per 4M distances, and the atomics
+        // need no extra VGPRs, which keeps the kernel inside the 80-register budget of 6 waves/SIMD without spills.
+        const int par = s & 1;
         uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < QPT; ++j) if (valid(j)) dmin = min(dmin, best[j] >> DSHIFT);
-        dmin = wave_min(dmin);
-        const int par = s & 1;
-        if (WAVES > 1) {
-            if (lane == 0) red_min[par][wave] = dmin;
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) dmin = min(dmin, red_min[par][w]);
-        }
+        atomicMin(&red_min[par], dmin);
+        __syncthreads();
+        dmin = red_min[par];
+        if (tid == 0) { red_min[par ^ 1] = 0xFFFFFFFFu; red_sum[par ^ 1] = 0u; }   // next pair's words (idle until B)
         uint32_t thr = (uint32_t)a.ratio * dmin;
         thr = max(thr, (uint32_t)a.dist_floor);
         uint32_t cnt = 0;
 #pragma unroll
         for (int j = 0; j < QPT; ++j) cnt += (valid(j) && (best[j] >> DSHIFT) <= thr) ? 1u : 0u;
-        cnt = wave_sum(cnt);
-        if (WAVES > 1) {
-            if (lane == 0) red_sum[par][wave] = cnt;
-            __syncthreads();
-            cnt = 0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) cnt += red_sum[par][w];
-        }
+        atomicAdd(&red_sum[par], cnt);
+        __syncthreads();
+        cnt = red_sum[par];
         if (tid == 0) {
             const bool empty = (nq <= 0) || (nt <= 0);
             uint2 rec;
