@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (A/B measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget; 0 disables")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores this process may use")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the N > 1 code path (process group, all-gather) even at world size 1")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU rehearsal of the N > 1 path)")
     args = ap.parse_args()
 
@@ -88,8 +89,12 @@ def main():
         local_rank %= torch.cuda.device_count()          # rehearsal: ranks may share a card
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -126,7 +131,7 @@ def main():
     frame_bytes = fs.stride_rows * 32
     for pos in owned:
         m.append_device(int(fs.ids[pos]), d_rows.data_ptr() + int(pos) * frame_bytes, int(fs.counts[pos]))
-    if world == 1:
+    if not multi:
         n_local, offs = m.all_vs_all_plan()
         q_args = dict()
     else:
@@ -135,7 +140,7 @@ def main():
         n_local, offs = m.all_vs_all_plan(**q_args)
     scores = torch.zeros(max(n_local, 1), dtype=torch.int64, device=dev)     # 8-byte lcm_score records
     cdev = dev if args.backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if multi:
         n_t = torch.tensor([n_local], dtype=torch.int64, device=cdev)
         lens = [torch.zeros_like(n_t) for _ in range(world)]
         dist.all_gather(lens, n_t)
@@ -147,7 +152,7 @@ def main():
         lens = [n_local]
 
     def step():
-        if world == 1:
+        if not multi:
             m.all_vs_all(scores.data_ptr(), n_local, **q_args)
         else:
             m.all_vs_all(send.data_ptr(), cap, **q_args)          # kernel writes straight into the send buffer
@@ -158,7 +163,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -173,7 +178,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
@@ -181,7 +186,7 @@ def main():
     kernel_ms.append(info.kernel_ms)
     # a few more individually timed launches for a stable per-launch duration (outside the timed region)
     for _ in range(min(3, max(args.steps - 1, 0))):
-        m.all_vs_all((send if world > 1 else scores).data_ptr(), cap if world > 1 else n_local, **q_args)
+        m.all_vs_all((send if multi else scores).data_ptr(), cap if multi else n_local, **q_args)
         kernel_ms.append(m.launch_info().kernel_ms)
     kern_ms = float(np.mean(kernel_ms))
 
@@ -192,22 +197,33 @@ def main():
         m.set_kernel_variant(1)
         ms = []
         for _ in range(2):
-            m.all_vs_all((send if world > 1 else scores).data_ptr(), cap if world > 1 else n_local, **q_args)
+            m.all_vs_all((send if multi else scores).data_ptr(), cap if multi else n_local, **q_args)
             ms.append(m.launch_info().kernel_ms)
         argmin_ms = float(np.mean(ms))
         m.set_kernel_variant(0)
-        m.all_vs_all((send if world > 1 else scores).data_ptr(), cap if world > 1 else n_local, **q_args)
+        m.all_vs_all((send if multi else scores).data_ptr(), cap if multi else n_local, **q_args)
         m.sync()
 
     tot = torch.tensor([local_dist, int(info.pairs), int(info.algo_bytes)], dtype=torch.int64, device=cdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     total_dist, total_pairs, total_bytes = (int(x) for x in tot.tolist())
     value = total_dist * args.steps / elapsed
 
     # ---- parity spot check + CPU baseline (rank 0, N = 1 only) ---------------------------------------
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if multi:
+        # merge check (outside the timed region): the gathered shards, un-permuted, must equal what a single device
+        # would have written for a sample of query frames — here verified structurally (lengths, n_train fields)
+        host = recv.view(world, cap).cpu().numpy()
+        shards = [host[r, : lens[r]].view(pkg.capi.SCORE_DTYPE) for r in range(world)]
+        merged, moffs = pkg.sharding.merge_shard_scores(shards, fs.ids, args.gap)
+        exp = pkg.synth.n_pairs_all_vs_all(n_frames, args.gap)
+        assert len(merged) == exp, (len(merged), exp)
+        e = pkg.sharding.eligible_counts(fs.ids, args.gap)
+        nt_expect = np.concatenate([fs.counts[: int(k)] for k in e]) if exp else np.zeros(0)
+        assert np.array_equal(merged["n_train"].astype(np.int64), nt_expect.astype(np.int64)), "merged shard order is wrong"
+    if rank == 0 and not multi and args.cpu_seconds > 0:
         oracle = entry.load_oracle()
         oracle.build()
         threads = args.cpu_threads or host_cores()
@@ -270,7 +286,7 @@ def main():
         }
         print(json.dumps(out))
     m.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
