@@ -10,6 +10,7 @@
  *                            LoopClosingSystem::matchFeatures makes (include/loop_closing.hpp:40,73)
  *   lcm_match_features    <- LoopClosingSystem::matchFeatures incl. the "2 x minimum distance"
  *                            filter (include/loop_closing.hpp:40, README.md:116-117)
+ *   lcm_match_stored      <- matchFeatures on two frames of frames_ (README.md:101 re-match of loop frames)
  *   lcm_db_append*        <- `frames_.push_back(frame)` inside processFrame
  *                            (include/loop_closing.hpp:34,69) — the stored-frame descriptor database
  *   lcm_query_scores      <- the per-stored-frame loop inside detectLoops
@@ -145,6 +146,12 @@ LCM_API int  lcm_match_pair(lcm_handle* h, const uint8_t* query, int nq, const u
  * `out` needs room for nq records. */
 LCM_API int  lcm_match_features(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
                                 lcm_dmatch* out, int* n_out, int* min_dist);
+
+/* matchFeatures between two STORED frames (device-resident rows, no upload): the "re-match features on identified
+ * loop frames" step (README.md:101) that turns a LoopCandidate into its DMatch list.  `out` needs room for the query
+ * frame's row count (cap). */
+LCM_API int  lcm_match_stored(lcm_handle* h, int query_frame_id, int train_frame_id,
+                              lcm_dmatch* out, int cap, int* n_out, int* min_dist);
 
 /* ---- loop search against the stored database --------------------------------------------------------- */
 /* Score `query` (id query_frame_id) against every stored frame with query_frame_id - id >= min_gap, ascending

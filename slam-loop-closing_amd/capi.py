@@ -81,6 +81,7 @@ _SIGNATURES = {
     "lcm_db_read": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
     "lcm_match_pair": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _i32p]),
     "lcm_match_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _i32p, _i32p]),
+    "lcm_match_stored": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _i32p, _i32p]),
     "lcm_query_scores": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _i32p]),
     "lcm_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
     "lcm_loop_test": (C.c_int, [C.POINTER(Params), C.POINTER(Score), C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -228,6 +229,14 @@ class Matcher:
         n, m = C.c_int32(0), C.c_int32(0)
         _check(self._lib.lcm_match_features(self._h, _ptr(q), q.shape[0], _ptr(t), t.shape[0],
                                             out.ctypes.data_as(_vp), C.byref(n), C.byref(m)))
+        return out[: n.value], m.value
+
+    def match_stored(self, query_frame_id: int, train_frame_id: int, cap: int = 65536) -> Tuple[np.ndarray, int]:
+        """matchFeatures between two stored frames (device-resident rows)."""
+        out = np.zeros(cap, DMATCH_DTYPE)
+        n, m = C.c_int32(0), C.c_int32(0)
+        _check(self._lib.lcm_match_stored(self._h, query_frame_id, train_frame_id, out.ctypes.data_as(_vp), cap,
+                                          C.byref(n), C.byref(m)))
         return out[: n.value], m.value
 
     # -- loop search -------------------------------------------------------------------------------

@@ -103,11 +103,12 @@ struct lcm_handle {
     uint8_t* d_qbuf = nullptr;  size_t d_qbuf_bytes = 0;
     int32_t* d_qcounts = nullptr; size_t d_qcounts_n = 0;
     uint8_t* d_tbuf = nullptr;  size_t d_tbuf_bytes = 0;
-    int32_t* d_tcounts = nullptr;
+    int32_t* d_tcounts = nullptr; size_t d_tcounts_n = 0;
     uint32_t* d_keys = nullptr; size_t d_keys_n = 0;
     lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
     lcm::WorkItem* d_items = nullptr; size_t d_items_n = 0;
     std::vector<lcm_score> h_scores;
+    std::vector<uint32_t> h_keys;
 
     Plan plan;
     lcm_launch_info info{};
@@ -451,43 +452,106 @@ int lcm_db_read(lcm_handle* h, int slot, uint8_t* desc_out, int cap_rows) {
 
 /* ---- pair mode --------------------------------------------------------------------------------------- */
 
-// Computes the best packed key of every query row against all train rows; h->d_keys holds them afterwards
-// (chunk c of up to 2048 rows at keys[c*2048 ...]).  Returns the keys on the host in `keys_out`.
-static int pair_keys(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt, std::vector<uint32_t>& keys_out) {
+// Row source of the pair mode: host rows (uploaded to scratch) or rows already on the device (a stored frame).
+struct RowSrc {
+    const uint8_t* host;
+    const uint8_t* dev;
+    int n;
+};
+
+// Best packed key (dist << 22 | GLOBAL train index) of every query row against all train rows -> keys_out[0..nq).
+//
+// One pair is cut into (query chunk of <= 2048 rows) x (train segment of SEG rows) work items so that a single
+// 2000 x 2000 match occupies ~60 workgroups instead of one (N2: consecutive-frame matching latency).  Each item is an
+// ordinary "query frame vs one stored frame" unit of the scoring kernel: the train matrix is addressed as pseudo-frames
+// of SEG rows.  Per-segment keys carry segment-local indices; the host folds them with the segment base, and because
+// the fold is a min over (dist, global index) keys the FIRST minimum still wins.
+static int pair_keys(lcm_handle* h, RowSrc q, RowSrc t, std::vector<uint32_t>& keys_out) {
     int rc = set_device(h); if (rc) return rc;
+    const int nq = q.n, nt = t.n;
     if (nt > LCM_MAX_TRAIN_ROWS) return fail(LCM_ERR_CAPACITY, "at most %d train rows per call", LCM_MAX_TRAIN_ROWS);
     const int CH = lcm::MAX_FUSED_QUERY_ROWS;
     const int n_chunks = (nq + CH - 1) / CH;
-    // query rows as n_chunks pseudo-frames of CH rows
-    rc = upload_rows(h, h->d_qbuf, h->d_qbuf_bytes, query, nq, n_chunks * CH, false); if (rc) return rc;
-    rc = upload_rows(h, h->d_tbuf, h->d_tbuf_bytes, train, nt, padded_rows(nt) + ROW_PAD, true); if (rc) return rc;
-    std::vector<int32_t> qc(n_chunks);
-    std::vector<lcm::WorkItem> items(n_chunks);
+    int n_seg = std::max(1, std::min((nt + 31) / 32, std::max(1, 512 / n_chunks)));
+    const int SEG = round_up((nt + n_seg - 1) / n_seg, ROW_PAD);
+    n_seg = (nt + SEG - 1) / SEG;
+    const uint8_t* d_q = q.dev;
+    const uint8_t* d_t = t.dev;
+    if (!d_q) { rc = upload_rows(h, h->d_qbuf, h->d_qbuf_bytes, q.host, nq, n_chunks * CH, false); if (rc) return rc; d_q = h->d_qbuf; }
+    if (!d_t) { rc = upload_rows(h, h->d_tbuf, h->d_tbuf_bytes, t.host, nt, padded_rows(nt) + ROW_PAD, true); if (rc) return rc; d_t = h->d_tbuf; }
+    else { rc = wait_db(h); if (rc) return rc; }
+    if (q.dev) { rc = wait_db(h); if (rc) return rc; }
+    const size_t n_items = (size_t)n_chunks * n_seg;
+    std::vector<int32_t> qc(n_chunks), tc(n_seg);
+    std::vector<lcm::WorkItem> items(n_items);
+    for (int g = 0; g < n_seg; ++g) tc[g] = std::min(SEG, nt - g * SEG);
     for (int c = 0; c < n_chunks; ++c) {
         qc[c] = std::min(CH, nq - c * CH);
-        items[c] = {(uint32_t)c, 0u, 1u, (uint32_t)c};
+        for (int g = 0; g < n_seg; ++g) items[(size_t)c * n_seg + g] = {(uint32_t)c, (uint32_t)g, 1u, (uint32_t)(c * n_seg + g)};
     }
     rc = ensure_dev(h->d_qcounts, h->d_qcounts_n, (size_t)n_chunks); if (rc) return rc;
-    if (!h->d_tcounts) HIP_TRY(hipMalloc((void**)&h->d_tcounts, 64));
-    rc = ensure_dev(h->d_items, h->d_items_n, (size_t)n_chunks); if (rc) return rc;
-    rc = ensure_dev(h->d_keys, h->d_keys_n, (size_t)n_chunks * CH); if (rc) return rc;
-    rc = ensure_dev(h->d_scores, h->d_scores_n, (size_t)n_chunks); if (rc) return rc;
-    int32_t ntc = nt;
+    rc = ensure_dev(h->d_tcounts, h->d_tcounts_n, (size_t)n_seg); if (rc) return rc;
+    rc = ensure_dev(h->d_items, h->d_items_n, n_items); if (rc) return rc;
+    rc = ensure_dev(h->d_keys, h->d_keys_n, n_items * CH); if (rc) return rc;
+    rc = ensure_dev(h->d_scores, h->d_scores_n, n_items); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->d_qcounts, qc.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_tcounts, &ntc, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_items, items.data(), sizeof(lcm::WorkItem) * n_chunks, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_tcounts, tc.data(), sizeof(int32_t) * n_seg, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_items, items.data(), sizeof(lcm::WorkItem) * n_items, hipMemcpyHostToDevice, h->stream));
     lcm::ScoreArgs a{};
-    a.q_rows = (const uint32_t*)h->d_qbuf; a.q_counts = h->d_qcounts; a.q_stride_words = CH * LCM_DESC_WORDS;
-    a.db_rows = (const uint32_t*)h->d_tbuf; a.db_counts = h->d_tcounts; a.db_stride_words = 0;
+    a.q_rows = (const uint32_t*)d_q; a.q_counts = h->d_qcounts; a.q_stride_words = CH * LCM_DESC_WORDS;
+    a.db_rows = (const uint32_t*)d_t; a.db_counts = h->d_tcounts; a.db_stride_words = (uint32_t)SEG * LCM_DESC_WORDS;
     a.items = h->d_items; a.scores = h->d_scores; a.keys = h->d_keys; a.keys_stride = CH;
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
-    int max_rows = n_chunks > 1 ? CH : nq;
-    rc = launch_and_time(h, a, (uint32_t)n_chunks, max_rows, true); if (rc) return rc;
+    const int max_rows = n_chunks > 1 ? CH : nq;
+    rc = launch_and_time(h, a, (uint32_t)n_items, max_rows, true); if (rc) return rc;
     h->info.pairs = 1; h->info.distances = (uint64_t)nq * nt;
     h->info.algo_bytes = (uint64_t)nt * 32 + (uint64_t)nq * 32 + 8;
-    keys_out.resize((size_t)n_chunks * CH);
-    HIP_TRY(hipMemcpyAsync(keys_out.data(), h->d_keys, sizeof(uint32_t) * keys_out.size(), hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint32_t>& raw = h->h_keys;
+    raw.resize(n_items * CH);
+    HIP_TRY(hipMemcpyAsync(raw.data(), h->d_keys, sizeof(uint32_t) * raw.size(), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    // fold the segments (integer bookkeeping on shipped keys; no distance is computed on the host)
+    keys_out.assign((size_t)nq, 0xFFFFFFFFu);
+    for (int c = 0; c < n_chunks; ++c)
+        for (int g = 0; g < n_seg; ++g) {
+            const uint32_t* src = raw.data() + ((size_t)c * n_seg + g) * CH;
+            uint32_t* dst = keys_out.data() + (size_t)c * CH;
+            const uint32_t base = (uint32_t)g * SEG;
+            for (int i = 0; i < qc[c]; ++i) dst[i] = std::min(dst[i], src[i] + base);
+        }
+    return LCM_OK;
+}
+
+// Device rows + row counts of a stored frame.
+static int stored_src(lcm_handle* h, int frame_id, RowSrc* out, int* n_kp) {
+    int lo = 0, hi = (int)h->frames.size();
+    while (lo < hi) { int mid = (lo + hi) / 2; if (h->frames[mid].id < frame_id) lo = mid + 1; else hi = mid; }
+    if (lo >= (int)h->frames.size() || h->frames[lo].id != frame_id) return fail(LCM_ERR_NOT_FOUND, "frame id %d is not stored", frame_id);
+    out->host = nullptr;
+    out->dev = h->d_rows + (size_t)lo * h->stride_rows * LCM_DESC_BYTES;
+    out->n = h->frames[lo].n;
+    if (n_kp) *n_kp = h->frames[lo].n_kp;
+    return LCM_OK;
+}
+
+static int filter_keys(const lcm_handle* h, const std::vector<uint32_t>& keys, int nq, lcm_dmatch* out, int* n_out, int* min_dist) {
+    // README.md:117 filter on the shipped integers (O(nq) bookkeeping)
+    uint32_t m = 0xFFFFFFFFu;
+    for (int i = 0; i < nq; ++i) m = std::min(m, keys[i] >> lcm::KEY_SHIFT);
+    const uint32_t thr = std::max((uint32_t)h->params.ratio * m, (uint32_t)h->params.dist_floor);
+    int k = 0;
+    for (int i = 0; i < nq; ++i) {
+        const uint32_t d = keys[i] >> lcm::KEY_SHIFT;
+        if (d <= thr) {
+            out[k].query_idx = i;
+            out[k].train_idx = (int32_t)(keys[i] & lcm::KEY_IDX_MASK);
+            out[k].img_idx = 0;
+            out[k].distance = (float)d;
+            ++k;
+        }
+    }
+    *n_out = k;
+    if (min_dist) *min_dist = (int)m;
     return LCM_OK;
 }
 
@@ -498,7 +562,7 @@ int lcm_match_pair(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* t
     if (nq == 0 || nt == 0) return LCM_OK;            // BFMatcher: no train rows => no matches
     if (!query || !train || !train_idx || !dist) return fail(LCM_ERR_INVALID_ARG, "NULL buffer");
     std::vector<uint32_t> keys;
-    int rc = pair_keys(h, query, nq, train, nt, keys); if (rc) return rc;
+    int rc = pair_keys(h, RowSrc{query, nullptr, nq}, RowSrc{train, nullptr, nt}, keys); if (rc) return rc;
     for (int i = 0; i < nq; ++i) {
         train_idx[i] = (int32_t)(keys[i] & lcm::KEY_IDX_MASK);
         dist[i] = (uint16_t)(keys[i] >> lcm::KEY_SHIFT);
@@ -515,25 +579,23 @@ int lcm_match_features(lcm_handle* h, const uint8_t* query, int nq, const uint8_
     if (nq == 0 || nt == 0) return LCM_OK;
     if (!query || !train || !out) return fail(LCM_ERR_INVALID_ARG, "NULL buffer");
     std::vector<uint32_t> keys;
-    int rc = pair_keys(h, query, nq, train, nt, keys); if (rc) return rc;
-    // README.md:117 filter on the shipped integers (O(nq) bookkeeping, no distance is computed here)
-    uint32_t m = 0xFFFFFFFFu;
-    for (int i = 0; i < nq; ++i) m = std::min(m, keys[i] >> lcm::KEY_SHIFT);
-    uint32_t thr = std::max((uint32_t)h->params.ratio * m, (uint32_t)h->params.dist_floor);
-    int k = 0;
-    for (int i = 0; i < nq; ++i) {
-        uint32_t d = keys[i] >> lcm::KEY_SHIFT;
-        if (d <= thr) {
-            out[k].query_idx = i;
-            out[k].train_idx = (int32_t)(keys[i] & lcm::KEY_IDX_MASK);
-            out[k].img_idx = 0;
-            out[k].distance = (float)d;
-            ++k;
-        }
-    }
-    *n_out = k;
-    if (min_dist) *min_dist = (int)m;
-    return LCM_OK;
+    int rc = pair_keys(h, RowSrc{query, nullptr, nq}, RowSrc{train, nullptr, nt}, keys); if (rc) return rc;
+    return filter_keys(h, keys, nq, out, n_out, min_dist);
+}
+
+int lcm_match_stored(lcm_handle* h, int query_frame_id, int train_frame_id, lcm_dmatch* out, int cap, int* n_out, int* min_dist) {
+    if (!h || !n_out) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    *n_out = 0;
+    if (min_dist) *min_dist = -1;
+    int rc = set_device(h); if (rc) return rc;
+    RowSrc q{}, t{};
+    rc = stored_src(h, query_frame_id, &q, nullptr); if (rc) return rc;
+    rc = stored_src(h, train_frame_id, &t, nullptr); if (rc) return rc;
+    if (q.n == 0 || t.n == 0) return LCM_OK;
+    if (!out || cap < q.n) return fail(LCM_ERR_CAPACITY, "need room for %d matches", q.n);
+    std::vector<uint32_t> keys;
+    rc = pair_keys(h, q, t, keys); if (rc) return rc;
+    return filter_keys(h, keys, q.n, out, n_out, min_dist);
 }
 
 /* ---- loop search ------------------------------------------------------------------------------------- */

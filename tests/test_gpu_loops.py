@@ -160,3 +160,23 @@ def test_errors_are_loud(matcher, pkg):
     with pytest.raises(pkg.LcmError):
         matcher.query_scores(np.zeros((2049, 32), np.uint8), 100)
     matcher.clear()
+
+
+def test_match_stored_equals_match_features(matcher, oracle, pkg):
+    """N1: the DMatch list of a detected loop, from device-resident rows (README.md:101 re-match)."""
+    fs = pkg.synth.make_frames(20, 700, seed=23, ragged=True, dup_frac=0.4)
+    fs.counts[6] = 0
+    matcher.set_params(min_gap=3)
+    try:
+        fill(matcher, fs)
+        for a, b in [(17, 1), (12, 12), (19, 4), (9, 6), (6, 2)]:
+            got, md = matcher.match_stored(int(fs.ids[a]), int(fs.ids[b]))
+            want, wmd = oracle.match_features(fs.frame(a), fs.frame(b), oracle.default_params(min_gap=3))
+            assert md == wmd and len(got) == len(want)
+            for f in ("query_idx", "train_idx", "img_idx", "distance"):
+                np.testing.assert_array_equal(got[f], want[f])
+        with pytest.raises(pkg.LcmError):
+            matcher.match_stored(999, 1)
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
