@@ -39,6 +39,7 @@ WORKLOADS = {
     "cfg2": (1000, 2000, "cfg2: 1000 frames x 2000 x 256-bit ORB descriptors, all-vs-all loop search, min_gap 30"),
     "cfg3": (10000, 2000, "cfg3: 10000 frames x 2000 descriptors, database sharded by frame across the GPUs"),
     "cfg4": (5000, 2000, "cfg4: 5000 frames x 2000 descriptors, fused on-device filter + loop-test counts"),
+    "cfg5": (20000, 2000, "cfg5: 20000 frames x 2000 descriptors (use --mode stream: per-frame append + query)"),
 }
 
 
@@ -54,18 +55,90 @@ def host_cores():
     return max(1, n)
 
 
+def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi, wl_desc, seed):
+    """Online mode: frames arrive one at a time as HOST rows.  Per frame: lcm_query_scores (H2D of the 64 KB query,
+    kernel over this rank's shard, D2H of the 8-byte records) and, if this rank owns the frame's position,
+    lcm_db_append (pinned staging + hipMemcpyAsync on the copy stream, overlapping the next frame's scoring).
+    One step = one pass over the whole sequence.  Scores are gathered once per step (RCCL) when N > 1."""
+    p = pkg.default_params()
+    p.min_gap = args.gap
+    stream = torch.cuda.current_stream(dev)
+    m = pkg.Matcher(p, device=local_rank, stream=stream.cuda_stream)
+    n_frames = fs.n_frames
+    owned_n = len(pkg.sharding.owned_positions(n_frames, rank, world))
+    m.reserve(owned_n, fs.stride_rows)
+    frames = [np.ascontiguousarray(fs.frame(f)) for f in range(n_frames)]
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")
+
+    def one_pass():
+        m.clear()
+        out, dist_n = [], 0
+        for f in range(n_frames):
+            sc, _ = m.query_scores(frames[f], int(fs.ids[f]))
+            out.append(sc)
+            dist_n += int(sc["n_train"].astype(np.int64).sum()) * frames[f].shape[0]
+            if f % world == rank:
+                m.append(int(fs.ids[f]), frames[f])
+        m.sync()
+        local = np.concatenate(out) if out else np.zeros(0, pkg.capi.SCORE_DTYPE)
+        if multi:
+            t = torch.from_numpy(local.view(np.int64).copy()).to(cdev)
+            shards = pkg.sharding.all_gather_scores(t, len(local))
+        else:
+            shards = [local]
+        return shards, dist_n
+
+    for _ in range(args.warmup):
+        one_pass()
+    torch.cuda.synchronize(dev)
+    if multi:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        shards, dist_n = one_pass()
+    torch.cuda.synchronize(dev)
+    if multi:
+        dist.barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([dist_n], dtype=torch.int64, device=cdev)
+    if multi:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed, total_dist = float(el.item()), int(tot.item())
+    merged, _ = pkg.sharding.merge_shard_scores(shards, fs.ids, args.gap)
+    assert len(merged) == pkg.synth.n_pairs_all_vs_all(n_frames, args.gap)
+    if rank == 0:
+        print(json.dumps({
+            "metric": METRIC, "value": total_dist * args.steps / elapsed, "unit": "distances/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak" if args.workload == "auto" else "strong", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "STREAMING (online append + per-frame query, host rows over PCIe): " + wl_desc,
+                       "frames": n_frames, "descriptors_per_frame": fs.stride_rows, "min_gap": args.gap,
+                       "pairs_per_step": len(merged), "distances_per_step": total_dist, "seed": seed,
+                       "sharding": "cyclic by frame" if world > 1 else "none"},
+            "roofline": None, "cpu_baseline": None,
+            "note": "PCIe-inclusive online rate; the headline metric is the batch mode (inputs resident in HBM)"}))
+    m.close()
+    if multi:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="auto", help="auto | cfg1 | cfg2 | cfg3 | cfg4")
+    ap.add_argument("--workload", default="auto", help="auto | cfg1 | cfg2 | cfg3 | cfg4 | cfg5")
     ap.add_argument("--frames", type=int, default=0, help="override the frame count")
     ap.add_argument("--desc", type=int, default=0, help="override descriptors per frame")
     ap.add_argument("--gap", type=int, default=30)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (A/B measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget; 0 disables")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores this process may use")
+    ap.add_argument("--mode", default="batch", help="batch (default: one all-vs-all pass per step) | stream (online: "
+                    "per frame, score it against the database, then append it — BASELINE.json configs[4] shape)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the N > 1 code path (process group, all-gather) even at world size 1")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU rehearsal of the N > 1 path)")
     args = ap.parse_args()
@@ -117,6 +190,9 @@ def main():
         n_frames = base_frames
     seed = pkg.synth.BASE_SEED + 2
     fs = pkg.synth.make_frames(n_frames, n_desc, seed=seed)
+
+    if args.mode == "stream":
+        return stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi, wl_desc, seed)
 
     # ---- inputs resident in HBM ----------------------------------------------------------------------
     d_rows = torch.from_numpy(fs.rows).to(dev)                 # (frames, stride, 32) uint8: the query stream

@@ -137,6 +137,11 @@ LCM_API int  lcm_db_frame_info(const lcm_handle* h, int slot, int* frame_id, int
 /* Copy a stored frame's rows back to the host (tests / snapshot). */
 LCM_API int  lcm_db_read(lcm_handle* h, int slot, uint8_t* desc_out, int cap_rows);
 
+/* Snapshot / restore of the stored-frame database (ids, row counts, keypoint counts, rows) as one raw file — the
+ * reference has no checkpointing; this makes long streaming runs resumable. */
+LCM_API int  lcm_db_save(lcm_handle* h, const char* path);
+LCM_API int  lcm_db_load(lcm_handle* h, const char* path);
+
 /* ---- pair mode: BFMatcher(NORM_HAMMING, crossCheck=false).match ------------------------------------ */
 /* For each query row q (ascending): train_idx[q] = FIRST index of the minimum Hamming distance over the
  * nt train rows, dist[q] = that distance.  nq == 0 or nt == 0: nothing is written, *n_matches = 0. */

@@ -79,6 +79,8 @@ _SIGNATURES = {
     "lcm_db_clear": (C.c_int, [_vp]),
     "lcm_db_frame_info": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
     "lcm_db_read": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    "lcm_db_save": (C.c_int, [_vp, C.c_char_p]),
+    "lcm_db_load": (C.c_int, [_vp, C.c_char_p]),
     "lcm_match_pair": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _i32p]),
     "lcm_match_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _i32p, _i32p]),
     "lcm_match_stored": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _i32p, _i32p]),
@@ -210,6 +212,12 @@ class Matcher:
         out = np.empty((n, DESC_BYTES), np.uint8)
         _check(self._lib.lcm_db_read(self._h, slot, _ptr(out) if n else None, n))
         return out
+
+    def save(self, path: str):
+        _check(self._lib.lcm_db_save(self._h, path.encode()))
+
+    def load(self, path: str):
+        _check(self._lib.lcm_db_load(self._h, path.encode()))
 
     # -- pair mode ---------------------------------------------------------------------------------
     def match_pair(self, query, train) -> Tuple[np.ndarray, np.ndarray]:

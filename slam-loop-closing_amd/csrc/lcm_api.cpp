@@ -450,6 +450,59 @@ int lcm_db_read(lcm_handle* h, int slot, uint8_t* desc_out, int cap_rows) {
     return LCM_OK;
 }
 
+/* ---- snapshot / restore (N4): raw little-endian file, no parsing of anything executable --------------------- */
+namespace {
+struct SnapHeader { char magic[8]; uint32_t version, n_frames, max_rows, reserved; };
+}
+
+int lcm_db_save(lcm_handle* h, const char* path) {
+    if (!h || !path) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    int rc = lcm_sync(h); if (rc) return rc;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(LCM_ERR_INVALID_ARG, "cannot open %s for writing", path);
+    SnapHeader hd{{'L', 'C', 'M', 'D', 'B', '0', '1', 0}, 1u, (uint32_t)h->frames.size(), 0u, 0u};
+    for (const FrameMeta& m : h->frames) hd.max_rows = std::max<uint32_t>(hd.max_rows, (uint32_t)m.n);
+    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1;
+    if (!h->frames.empty()) ok = ok && fwrite(h->frames.data(), sizeof(FrameMeta), h->frames.size(), f) == h->frames.size();
+    std::vector<uint8_t> buf;
+    for (size_t s = 0; ok && s < h->frames.size(); ++s) {
+        const size_t bytes = (size_t)h->frames[s].n * LCM_DESC_BYTES;
+        if (!bytes) continue;
+        buf.resize(bytes);
+        if (hipMemcpy(buf.data(), h->d_rows + s * (size_t)h->stride_rows * LCM_DESC_BYTES, bytes, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = fwrite(buf.data(), 1, bytes, f) == bytes;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? LCM_OK : fail(LCM_ERR_HIP, "writing %s failed", path);
+}
+
+int lcm_db_load(lcm_handle* h, const char* path) {
+    if (!h || !path) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(LCM_ERR_NOT_FOUND, "cannot open %s", path);
+    SnapHeader hd{};
+    std::vector<FrameMeta> metas;
+    int rc = LCM_OK;
+    if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "LCMDB01", 8) != 0 || hd.version != 1 || hd.max_rows > 65535u)
+        rc = fail(LCM_ERR_INVALID_ARG, "%s is not an lcm database snapshot", path);
+    if (!rc) {
+        metas.resize(hd.n_frames);
+        if (hd.n_frames && fread(metas.data(), sizeof(FrameMeta), hd.n_frames, f) != hd.n_frames) rc = fail(LCM_ERR_INVALID_ARG, "%s is truncated", path);
+    }
+    if (!rc) rc = lcm_db_clear(h);
+    if (!rc) rc = lcm_db_reserve(h, (int)hd.n_frames, (int)std::max<uint32_t>(hd.max_rows, 1));
+    std::vector<uint8_t> buf;
+    for (size_t s = 0; !rc && s < metas.size(); ++s) {
+        if (metas[s].n < 0 || (uint32_t)metas[s].n > hd.max_rows) { rc = fail(LCM_ERR_INVALID_ARG, "%s: bad row count", path); break; }
+        buf.resize((size_t)metas[s].n * LCM_DESC_BYTES + 1);
+        if (metas[s].n && fread(buf.data(), LCM_DESC_BYTES, (size_t)metas[s].n, f) != (size_t)metas[s].n) { rc = fail(LCM_ERR_INVALID_ARG, "%s is truncated", path); break; }
+        rc = lcm_db_append(h, metas[s].id, buf.data(), metas[s].n, metas[s].n_kp);
+    }
+    fclose(f);
+    if (!rc) rc = lcm_sync(h);
+    return rc;
+}
+
 /* ---- pair mode --------------------------------------------------------------------------------------- */
 
 // Row source of the pair mode: host rows (uploaded to scratch) or rows already on the device (a stored frame).

@@ -180,3 +180,31 @@ def test_match_stored_equals_match_features(matcher, oracle, pkg):
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+def test_snapshot_restore_round_trip(matcher, pkg, tmp_path):
+    fs = pkg.synth.make_frames(17, 260, seed=29, ragged=True)
+    fs.counts[3] = 0
+    matcher.set_params(min_gap=2)
+    try:
+        fill(matcher, fs)
+        before, offs = gpu_all_vs_all(matcher)
+        path = str(tmp_path / "db.lcm")
+        matcher.save(path)
+        matcher.clear()
+        assert len(matcher) == 0
+        matcher.load(path)
+        assert len(matcher) == fs.n_frames
+        for slot in (0, 3, 16):
+            assert matcher.frame_info(slot) == (int(fs.ids[slot]), int(fs.counts[slot]), int(fs.counts[slot]))
+            np.testing.assert_array_equal(matcher.read_frame(slot), fs.frame(slot))
+        after, offs2 = gpu_all_vs_all(matcher)
+        np.testing.assert_array_equal(before, after)
+        np.testing.assert_array_equal(offs, offs2)
+        with open(path, "r+b") as f:
+            f.write(b"garbage!")
+        with pytest.raises(pkg.LcmError):
+            matcher.load(path)
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
