@@ -365,7 +365,7 @@ int lcm_sync(lcm_handle* h) {
 
 int lcm_set_kernel_variant(lcm_handle* h, int variant) {
     if (!h) return fail(LCM_ERR_INVALID_ARG, "NULL handle");
-    if (variant < 0 || variant > 1) return fail(LCM_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
+    if (variant < 0 || variant > 3) return fail(LCM_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
     h->variant = variant;
     return LCM_OK;
 }

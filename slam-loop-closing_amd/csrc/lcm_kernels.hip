@@ -18,9 +18,9 @@
 //   * per pair, the min-of-mins and the good-match count are LDS-atomic reductions (ds_min_u32 / ds_add_u32) over
 //     the workgroup's lanes.
 //
-// Variant 1 — "train-row-per-lane, queries staged in LDS" (the mapping BASELINE.json's north_star sketches):
+// k_score_trainlane — "train-row-per-lane, queries staged in LDS" (the mapping BASELINE.json's north_star sketches):
 //   lanes own train rows (coalesced loads), query rows are broadcast from LDS, per-query min/argmin is a
-//   wavefront reduction per query.  Kept for A/B measurement; see DESIGN.md for the numbers.
+//   wavefront __shfl reduction per query.  Kept for A/B measurement; see DESIGN.md for the numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -212,6 +212,158 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Variant 1: the mapping BASELINE.json's north_star sketches — lanes own TRAIN rows (coalesced 16-byte loads, 8 rows
+// per lane = a whole 2048-row stored frame in a workgroup's registers), QUERY rows staged in LDS in 256-row tiles and
+// broadcast to all lanes with ds_read_b128, per-query min(/argmin) by a wavefront __shfl_xor reduction, waves combined
+// with ds_min_u32.  Kept selectable (lcm_set_kernel_variant(2) / 3) so that the choice of variant 0 rests on a
+// measurement: this mapping needs ~1.2 (distances) to ~2.2 (keys) extra 4-cycle VALU ops per distance for the
+// cross-lane reduction, see DESIGN.md §4.
+// ---------------------------------------------------------------------------------------------------
+// one broadcast query row (8 VGPRs, same value in every lane) against TWO of this lane's train rows
+__device__ __forceinline__ void fold2_vv(uint32_t& best, const uint32_t (&q)[8], const uint32_t (&t0)[8], const uint32_t (&t1)[8]) {
+    uint32_t d0, d1, x;
+    asm volatile(
+        "v_xor_b32_e32 %3, %4, %12\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, 0\n\t"
+        "v_xor_b32_e32 %3, %5, %13\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %6, %14\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %7, %15\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %8, %16\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %9, %17\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %10, %18\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %11, %19\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %4, %20\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, 0\n\t"
+        "v_xor_b32_e32 %3, %5, %21\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %6, %22\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %7, %23\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %8, %24\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %9, %25\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %10, %26\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %11, %27\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_min3_u32 %0, %0, %1, %2"
+        : "+v"(best), "=&v"(d0), "=&v"(d1), "=&v"(x)
+        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]),
+          "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t0[4]), "v"(t0[5]), "v"(t0[6]), "v"(t0[7]),
+          "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]), "v"(t1[4]), "v"(t1[5]), "v"(t1[6]), "v"(t1[7]));
+}
+// same, folding packed keys dist << 22 | train row (k0, k1 = this lane's two row indices)
+__device__ __forceinline__ void fold2_vv_keys(uint32_t& best, const uint32_t (&q)[8], const uint32_t (&t0)[8], const uint32_t (&t1)[8],
+                                              uint32_t k0, uint32_t k1) {
+    uint32_t d0, d1, x;
+    asm volatile(
+        "v_xor_b32_e32 %3, %4, %12\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, 0\n\t"
+        "v_xor_b32_e32 %3, %5, %13\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %6, %14\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %7, %15\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %8, %16\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %9, %17\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %10, %18\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %11, %19\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_xor_b32_e32 %3, %4, %20\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, 0\n\t"
+        "v_xor_b32_e32 %3, %5, %21\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %6, %22\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %7, %23\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %8, %24\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %9, %25\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %10, %26\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_xor_b32_e32 %3, %11, %27\n\ts_nop 0\n\tv_bcnt_u32_b32 %2, %3, %2\n\t"
+        "v_lshl_or_b32 %1, %1, 22, %28\n\t"
+        "v_lshl_or_b32 %2, %2, 22, %29\n\t"
+        "v_min3_u32 %0, %0, %1, %2"
+        : "+v"(best), "=&v"(d0), "=&v"(d1), "=&v"(x)
+        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]),
+          "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t0[4]), "v"(t0[5]), "v"(t0[6]), "v"(t0[7]),
+          "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]), "v"(t1[4]), "v"(t1[5]), "v"(t1[6]), "v"(t1[7]),
+          "v"(k0), "v"(k1));
+}
+
+template <bool ARGMIN, bool WRITE_KEYS>
+__global__ __launch_bounds__(256) void k_score_trainlane(ScoreArgs a) {
+    constexpr int THREADS = 256, TPT = 8, QTILE = 256;
+    constexpr int DSHIFT = ARGMIN ? KEY_SHIFT : 0;
+    __shared__ uint4 qtile[QTILE * 2];                 // 256 query rows x 32 bytes
+    __shared__ uint32_t best_q[THREADS * TPT];         // per query row: best distance / key of this pair
+    __shared__ uint32_t red_min, red_sum;
+
+    const int tid = threadIdx.x;
+    const WorkItem it = a.items[blockIdx.x];
+    const int nq = a.q_counts[it.q_frame];
+    const uint4* qbase = reinterpret_cast<const uint4*>(a.q_rows + (size_t)it.q_frame * a.q_stride_words);
+
+    for (uint32_t s = 0; s < it.n_slots; ++s) {
+        const uint32_t slot = it.slot_begin + s;
+        const int nt = a.db_counts[slot];
+        const uint4* tbase = reinterpret_cast<const uint4*>(a.db_rows + (size_t)slot * a.db_stride_words);
+        // this lane's train rows j*256 + tid; rows past the end are copies of the LAST row (same distance, higher
+        // index: can never win), so no lane needs masking in the inner loop
+        uint32_t t[TPT][8];
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+            int row = j * THREADS + tid;
+            row = row < nt ? row : max(nt - 1, 0);
+            const uint4 lo = tbase[row * 2], hi = tbase[row * 2 + 1];
+            t[j][0] = lo.x; t[j][1] = lo.y; t[j][2] = lo.z; t[j][3] = lo.w;
+            t[j][4] = hi.x; t[j][5] = hi.y; t[j][6] = hi.z; t[j][7] = hi.w;
+        }
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) best_q[j * THREADS + tid] = 0xFFFFFFFFu;
+        if (tid == 0) { red_min = 0xFFFFFFFFu; red_sum = 0u; }
+
+        for (int q0 = 0; q0 < nq && nt > 0; q0 += QTILE) {
+            __syncthreads();                                        // previous tile fully consumed (and best_q init visible)
+            if (q0 + tid < nq) { qtile[tid * 2] = qbase[(q0 + tid) * 2]; qtile[tid * 2 + 1] = qbase[(q0 + tid) * 2 + 1]; }
+            __syncthreads();
+            const int nrows = min(QTILE, nq - q0);
+            for (int i = 0; i < nrows; ++i) {
+                const uint4 lo = qtile[i * 2], hi = qtile[i * 2 + 1];      // same address in every lane: LDS broadcast
+                const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                uint32_t b = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < TPT; j += 2) {
+                    if (ARGMIN) fold2_vv_keys(b, q, t[j], t[j + 1], (uint32_t)(j * THREADS + tid), (uint32_t)((j + 1) * THREADS + tid));
+                    else fold2_vv(b, q, t[j], t[j + 1]);
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) b = min(b, (uint32_t)__shfl_xor((int)b, o, 64));   // wavefront reduction
+                if ((tid & 63) == 0) atomicMin(&best_q[q0 + i], b);                                    // 4 waves -> 1
+            }
+        }
+        __syncthreads();
+        // ---- pair epilogue (same record as variant 0)
+        const size_t out = (size_t)it.out_offset + s;
+        uint32_t dmin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+            const int row = j * THREADS + tid;
+            if (row < nq) {
+                const uint32_t k = best_q[row];
+                if (WRITE_KEYS) a.keys[out * a.keys_stride + row] = k;
+                dmin = min(dmin, k >> DSHIFT);
+            }
+        }
+        atomicMin(&red_min, dmin);
+        __syncthreads();
+        dmin = red_min;
+        uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+            const int row = j * THREADS + tid;
+            cnt += (row < nq && (best_q[row] >> DSHIFT) <= thr) ? 1u : 0u;
+        }
+        atomicAdd(&red_sum, cnt);
+        __syncthreads();
+        if (tid == 0) {
+            const bool empty = (nq <= 0) || (nt <= 0);
+            uint2 rec;
+            rec.x = empty ? 0u : red_sum;
+            rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
+            reinterpret_cast<uint2*>(a.scores)[out] = rec;
+        }
+        __syncthreads();                                            // red_* / best_q are rewritten by the next slot
+    }
+}
+
 // Occupancy throttle: dynamic LDS that the kernel never touches, sized so that exactly `waves_per_simd` workgroups of
 // 256 threads fit a CU's 160 KiB (6 is the measured optimum; the register budget is 80 VGPRs).
 static unsigned lds_pad_bytes() {
@@ -237,11 +389,21 @@ static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool writ
     return hipGetLastError();
 }
 
-// variant 0: bulk scoring tracks distances only (default); variant 1: bulk scoring tracks full (dist, idx) keys too
-// (the kernel the pair mode always uses) — kept selectable so both can be measured on the same workload.
+// variant 0: row-per-lane, bulk scoring tracks distances only (default)
+// variant 1: row-per-lane, bulk scoring tracks full (dist, idx) keys too (the kernel the pair mode always uses)
+// variant 2 / 3: north_star's train-row-per-lane mapping, distances only / keys (stored frames of <= 2048 rows)
+// All selectable so they can be measured on the same workload (bench.py --variant N).
 hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
                         hipStream_t st) {
-    const bool argmin = write_keys || variant == 1;
+    if (variant >= 2 && max_query_rows <= 2048 && a.db_stride_words != 0 && a.db_stride_words <= 2048 * 8) {
+        if (n_items == 0) return hipSuccess;
+        const bool argmin = write_keys || variant == 3;
+        if (write_keys) hipLaunchKernelGGL((k_score_trainlane<true, true>), dim3(n_items), dim3(256), 0, st, a);
+        else if (argmin) hipLaunchKernelGGL((k_score_trainlane<true, false>), dim3(n_items), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_score_trainlane<false, false>), dim3(n_items), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
+    const bool argmin = write_keys || variant == 1 || variant == 3;
     if (max_query_rows <= 512) return launch_rowlane<64, 8>(a, n_items, write_keys, argmin, st);
     if (max_query_rows <= 1024) return launch_rowlane<128, 8>(a, n_items, write_keys, argmin, st);
     if (max_query_rows <= 1536) return launch_rowlane<192, 8>(a, n_items, write_keys, argmin, st);

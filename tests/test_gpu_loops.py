@@ -208,3 +208,29 @@ def test_snapshot_restore_round_trip(matcher, pkg, tmp_path):
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_every_kernel_variant_is_bit_exact(matcher, oracle, pkg, variant):
+    """0/1: row-per-lane (distances / keys); 2/3: north_star's train-row-per-lane mapping with LDS-staged queries."""
+    fs = pkg.synth.make_frames(26, 700, seed=41, ragged=True, dup_frac=0.4)
+    fs.counts[4] = 0
+    fs.counts[9] = 1
+    gap = 3
+    matcher.set_params(min_gap=gap)
+    matcher.set_kernel_variant(variant)
+    try:
+        fill(matcher, fs)
+        got, offs = gpu_all_vs_all(matcher)
+        want, woffs = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap))
+        np.testing.assert_array_equal(got, want)
+        # pair mode (keys) through the same variant
+        for a, b in [(20, 2), (11, 9), (9, 11), (25, 4)]:
+            idx, d = matcher.match_pair(fs.frame(a), fs.frame(b))
+            oi, od = oracle.bf_match(fs.frame(a), fs.frame(b))
+            np.testing.assert_array_equal(idx, oi)
+            np.testing.assert_array_equal(d.astype(np.int32), od)
+    finally:
+        matcher.set_kernel_variant(0)
+        matcher.set_params(min_gap=30)
+        matcher.clear()
