@@ -234,3 +234,27 @@ def test_every_kernel_variant_is_bit_exact(matcher, oracle, pkg, variant):
         matcher.set_kernel_variant(0)
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+def test_arena_grows_in_frames_and_rows(pkg, oracle):
+    """No lcm_db_reserve: the arena must re-pitch (more rows per frame) and re-size (more frames) transparently."""
+    rng = np.random.default_rng(6)
+    sizes = [50, 120, 7, 2100, 300] + [40] * 80 + [2500, 3]
+    frames = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for n in sizes]
+    p = pkg.default_params()
+    p.min_gap = 1
+    with pkg.Matcher(p) as m:
+        for i, f in enumerate(frames):
+            m.append(i * 2, f)
+        assert len(m) == len(frames)
+        for slot in (0, 3, 4, 60, len(frames) - 2, len(frames) - 1):
+            np.testing.assert_array_equal(m.read_frame(slot), frames[slot])
+        q = frames[1]
+        scores, ids = m.query_scores(q, 2 * len(frames))
+        assert ids.tolist() == [2 * i for i in range(len(frames))]
+        op = oracle.default_params(min_gap=1)
+        for slot in (0, 3, 4, 60, len(frames) - 2, len(frames) - 1):
+            assert scores[slot] == oracle.pair_score(q, frames[slot], op)
+        # frames wider than one workgroup's 2048 rows can be stored and matched against, but not used as a query
+        with pytest.raises(pkg.LcmError):
+            m.detect_loops(2 * (len(frames) - 2))
