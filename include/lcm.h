@@ -181,6 +181,14 @@ LCM_API int  lcm_loop_test(const lcm_params* p, const lcm_score* s, int n_query_
 LCM_API int  lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
                             const int32_t* q_ids, int n_q_frames, int q_stride_rows,
                             void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets);
+/* Same search with the loop test fused on the device (README.md:123-126; BASELINE.json configs[3]): scores never
+ * leave HBM, a second kernel applies similarity > threshold && good >= min_matches per pair in IEEE double and
+ * compacts the candidates; `out` (host) receives them sorted by (current_frame_id, matched_frame_id).
+ * q_keypoints (host, optional) = keypoint counts of an external query set (NULL: row counts).  *n_out = number
+ * found (LCM_ERR_CAPACITY if > cap); *n_pairs_out (optional) = pairs scored. */
+LCM_API int  lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
+                                  const int32_t* q_ids, const int32_t* q_keypoints, int n_q_frames, int q_stride_rows,
+                                  lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out);
 LCM_API int  lcm_last_launch_info(const lcm_handle* h, lcm_launch_info* info);
 
 /* Select the pair-match kernel variant: 0 = default, see DESIGN.md (for A/B measurement only). */

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "lcm_loop_test": (C.c_int, [C.POINTER(Params), C.POINTER(Score), C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lcm_all_vs_all": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
                                   C.POINTER(C.c_size_t), _vp]),
+    "lcm_all_vs_all_loops": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lcm_last_launch_info": (C.c_int, [_vp, C.POINTER(LaunchInfo)]),
     "lcm_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
     "lcm_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
@@ -303,6 +305,20 @@ class Matcher:
                                         _vp(d_query_counts) if d_query_counts else None, _ptr(ids), nq, q_stride_rows,
                                         _vp(d_scores), scores_cap, C.byref(n), None))
         return n.value
+
+    def all_vs_all_loops(self, cap: int = 1 << 20, d_query_rows: int = 0, d_query_counts: int = 0,
+                         q_ids: Optional[Sequence[int]] = None, q_keypoints: Optional[Sequence[int]] = None,
+                         q_stride_rows: int = 0) -> Tuple[np.ndarray, int]:
+        """Bulk loop search with the loop test fused on the device: (candidates sorted by (current, matched), n_pairs)."""
+        ids = None if q_ids is None else np.ascontiguousarray(q_ids, np.int32)
+        kps = None if q_keypoints is None else np.ascontiguousarray(q_keypoints, np.int32)
+        nq = len(self) if ids is None else ids.shape[0]
+        out = np.zeros(max(cap, 1), CANDIDATE_DTYPE)
+        n, npairs = C.c_size_t(0), C.c_size_t(0)
+        _check(self._lib.lcm_all_vs_all_loops(self._h, _vp(d_query_rows) if d_query_rows else None,
+                                              _vp(d_query_counts) if d_query_counts else None, _ptr(ids), _ptr(kps), nq,
+                                              q_stride_rows, out.ctypes.data_as(_vp), cap, C.byref(n), C.byref(npairs)))
+        return out[: n.value], npairs.value
 
     def launch_info(self) -> LaunchInfo:
         info = LaunchInfo()

@@ -109,6 +109,9 @@ struct lcm_handle {
     lcm::WorkItem* d_items = nullptr; size_t d_items_n = 0;
     std::vector<lcm_score> h_scores;
     std::vector<uint32_t> h_keys;
+    lcm_score* d_bulk_scores = nullptr; size_t d_bulk_scores_n = 0;   // lcm_all_vs_all_loops: scores stay on the device
+    int32_t* d_meta = nullptr; size_t d_meta_n = 0;
+    lcm_loop_candidate* d_cands = nullptr; size_t d_cands_n = 0;
 
     Plan plan;
     lcm_launch_info info{};
@@ -328,6 +331,7 @@ void lcm_destroy(lcm_handle* h) {
     (void)hipFree(h->d_rows); (void)hipFree(h->d_counts);
     (void)hipFree(h->d_qbuf); (void)hipFree(h->d_qcounts); (void)hipFree(h->d_tbuf); (void)hipFree(h->d_tcounts);
     (void)hipFree(h->d_keys); (void)hipFree(h->d_scores); (void)hipFree(h->d_items); (void)hipFree(h->plan.d_items);
+    (void)hipFree(h->d_bulk_scores); (void)hipFree(h->d_meta); (void)hipFree(h->d_cands);
     for (int i = 0; i < STAGE_BUFS; ++i) {
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
@@ -852,6 +856,74 @@ int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_que
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
     rc = launch_and_time(h, a, (uint32_t)P.items.size(), P.max_q_rows, false); if (rc) return rc;
     h->info.pairs = P.n_pairs; h->info.distances = P.distances; h->info.algo_bytes = P.algo_bytes;
+    return LCM_OK;
+}
+
+// Bulk loop search with the loop test fused on the device: all-vs-all scores stay in device memory, a second tiny
+// kernel applies README.md:123-126 per pair and compacts the candidates; only those cross PCIe.
+int lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
+                         const int32_t* q_ids, const int32_t* q_keypoints, int n_q_frames, int q_stride_rows,
+                         lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out) {
+    if (!h || !n_out) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    *n_out = 0;
+    int rc = set_device(h); if (rc) return rc;
+    const bool self = (d_query_rows == nullptr);
+    size_t n_pairs = 0;
+    rc = lcm_all_vs_all(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, nullptr, 0, &n_pairs, nullptr);
+    if (rc) return rc;
+    if (n_pairs_out) *n_pairs_out = n_pairs;
+    if (n_pairs == 0) return LCM_OK;
+    rc = ensure_dev(h->d_bulk_scores, h->d_bulk_scores_n, n_pairs); if (rc) return rc;
+    rc = lcm_all_vs_all(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, h->d_bulk_scores, n_pairs, &n_pairs, nullptr);
+    if (rc) return rc;
+    const Plan& P = h->plan;
+    const int nq = self ? (int)h->frames.size() : n_q_frames;
+    const int ns = (int)h->frames.size();
+    // metadata the loop test needs, as one upload: offsets | q_ids | q_kp | db_ids | db_kp
+    std::vector<int32_t> meta((size_t)(nq + 1) + 2 * (size_t)nq + 2 * (size_t)ns);
+    int32_t* m_off = meta.data();
+    int32_t* m_qid = m_off + (nq + 1);
+    int32_t* m_qkp = m_qid + nq;
+    int32_t* m_did = m_qkp + nq;
+    int32_t* m_dkp = m_did + ns;
+    for (int c = 0; c <= nq; ++c) m_off[c] = (int32_t)(uint32_t)P.offsets[c];
+    std::vector<int32_t> qc;
+    if (!self && !q_keypoints) {           // external query set without keypoint counts: rows == keypoints (ORB)
+        qc.resize((size_t)nq);
+        HIP_TRY(hipMemcpy(qc.data(), d_query_counts, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
+    }
+    for (int c = 0; c < nq; ++c) {
+        m_qid[c] = self ? h->frames[c].id : q_ids[c];
+        m_qkp[c] = self ? h->frames[c].n_kp : (q_keypoints ? q_keypoints[c] : qc[c]);
+    }
+    for (int s = 0; s < ns; ++s) { m_did[s] = h->frames[s].id; m_dkp[s] = h->frames[s].n_kp; }
+    rc = ensure_dev(h->d_meta, h->d_meta_n, meta.size() + 4); if (rc) return rc;
+    const size_t dev_cap = std::max<size_t>(std::min<size_t>(cap, n_pairs), 1);
+    rc = ensure_dev(h->d_cands, h->d_cands_n, dev_cap); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_meta, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice, h->stream));
+    uint32_t* d_counter = reinterpret_cast<uint32_t*>(h->d_meta + meta.size());
+    HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), h->stream));
+    lcm::LoopTestArgs a{};
+    a.scores = h->d_bulk_scores;
+    a.offsets = reinterpret_cast<const uint32_t*>(h->d_meta);
+    a.q_ids = h->d_meta + (nq + 1); a.q_kp = a.q_ids + nq; a.db_ids = a.q_kp + nq; a.db_kp = a.db_ids + ns;
+    a.out = h->d_cands; a.counter = d_counter;
+    a.n_q = (uint32_t)nq; a.n_pairs = (uint32_t)n_pairs; a.cap = (uint32_t)dev_cap;
+    a.min_matches = h->params.min_matches; a.sim_threshold = h->params.sim_threshold;
+    hipError_t e = lcm::launch_loop_test(a, h->stream);
+    if (e != hipSuccess) return fail(LCM_ERR_HIP, "loop-test kernel launch failed: %s", hipGetErrorString(e));
+    uint32_t found = 0;
+    HIP_TRY(hipMemcpyAsync(&found, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *n_out = found;
+    if (found > cap || !out) return found ? fail(LCM_ERR_CAPACITY, "%u loop candidates but room for %zu", found, cap) : LCM_OK;
+    if (found) {
+        HIP_TRY(hipMemcpy(out, h->d_cands, sizeof(lcm_loop_candidate) * found, hipMemcpyDeviceToHost));
+        std::sort(out, out + found, [](const lcm_loop_candidate& x, const lcm_loop_candidate& y) {
+            return x.current_frame_id != y.current_frame_id ? x.current_frame_id < y.current_frame_id
+                                                            : x.matched_frame_id < y.matched_frame_id;
+        });
+    }
     return LCM_OK;
 }
 

@@ -38,4 +38,23 @@ struct ScoreArgs {
 hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
                         hipStream_t st);
 
+// On-device loop test over a finished score array (BASELINE.json configs[3] "fused on-device filter + loop test"):
+// pair p belongs to query frame c = upper_bound(offsets, p) - 1 and stored slot p - offsets[c]; a candidate is
+// similarity = good / min(kp_q, kp_t) > sim_threshold (IEEE double, strict) and good >= min_matches.  Candidates
+// are appended through an atomic counter (order restored on the host: (current id, matched id) is a total order).
+struct LoopTestArgs {
+    const void*     scores;        // lcm_score records
+    const uint32_t* offsets;       // n_q + 1 pair offsets per query frame
+    const int32_t*  q_ids;         // per query frame
+    const int32_t*  q_kp;          // keypoint count per query frame
+    const int32_t*  db_ids;        // per stored slot
+    const int32_t*  db_kp;
+    void*           out;           // lcm_loop_candidate records (24 bytes)
+    uint32_t*       counter;       // number of candidates found (may exceed cap: count only)
+    uint32_t        n_q, n_pairs, cap;
+    int32_t         min_matches;
+    double          sim_threshold;
+};
+hipError_t launch_loop_test(const LoopTestArgs& a, hipStream_t st);
+
 }  // namespace lcm

@@ -389,6 +389,43 @@ static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool writ
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// On-device loop test (README.md:123-126) over the score array: one thread per pair, candidates compacted with an
+// atomic counter.  The division is IEEE double (no fast-math), so the verdict is bit-identical to the host's.
+// ---------------------------------------------------------------------------------------------------
+struct CandidateRec { int32_t cur, matched, num; int32_t pad; double sim; };
+static_assert(sizeof(CandidateRec) == 24, "lcm_loop_candidate layout");
+
+__global__ __launch_bounds__(256) void k_loop_test(LoopTestArgs a) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= a.n_pairs) return;
+    // query frame of pair p: last c with offsets[c] <= p
+    uint32_t lo = 0, hi = a.n_q;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.offsets[mid] <= p) lo = mid; else hi = mid;
+    }
+    const uint32_t c = lo, slot = p - a.offsets[c];
+    const uint2 rec = reinterpret_cast<const uint2*>(a.scores)[p];
+    const uint32_t good = rec.x;
+    const int den = min(a.q_kp[c], a.db_kp[slot]);
+    if (den <= 0 || (int64_t)good < (int64_t)a.min_matches) return;
+    const double sim = (double)good / (double)den;
+    if (!(sim > a.sim_threshold)) return;
+    const uint32_t k = atomicAdd(a.counter, 1u);
+    if (k < a.cap) {
+        CandidateRec r;
+        r.cur = a.q_ids[c]; r.matched = a.db_ids[slot]; r.num = (int32_t)good; r.pad = 0; r.sim = sim;
+        reinterpret_cast<CandidateRec*>(a.out)[k] = r;
+    }
+}
+
+hipError_t launch_loop_test(const LoopTestArgs& a, hipStream_t st) {
+    if (a.n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_loop_test, dim3((a.n_pairs + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 // variant 0: row-per-lane, bulk scoring tracks distances only (default)
 // variant 1: row-per-lane, bulk scoring tracks full (dist, idx) keys too (the kernel the pair mode always uses)
 // variant 2 / 3: north_star's train-row-per-lane mapping, distances only / keys (stored frames of <= 2048 rows)

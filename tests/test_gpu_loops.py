@@ -258,3 +258,36 @@ def test_arena_grows_in_frames_and_rows(pkg, oracle):
         # frames wider than one workgroup's 2048 rows can be stored and matched against, but not used as a query
         with pytest.raises(pkg.LcmError):
             m.detect_loops(2 * (len(frames) - 2))
+
+
+def test_fused_on_device_loop_test(matcher, oracle, pkg):
+    """configs[3] shape: scores stay on the device, the loop test runs there, only candidates come back."""
+    fs = pkg.synth.make_frames(60, 500, seed=21, ragged=True, dup_frac=0.3)
+    fs.counts[7] = 0
+    gap = 10
+    matcher.set_params(min_gap=gap)
+    try:
+        matcher.clear()
+        for f in range(fs.n_frames):
+            # keypoint counts that differ from the row counts exercise the similarity denominator
+            matcher.append(int(fs.ids[f]), fs.frame(f), n_keypoints=int(fs.counts[f]) + (f % 3))
+        got, n_pairs = matcher.all_vs_all_loops()
+        assert n_pairs == pkg.synth.n_pairs_all_vs_all(fs.n_frames, gap)
+        p = oracle.default_params(min_gap=gap)
+        want = []
+        for c in range(fs.n_frames):
+            for i in range(fs.n_frames):
+                if fs.ids[c] - fs.ids[i] >= gap:
+                    s = oracle.pair_score(fs.frame(c), fs.frame(i), p)
+                    ok, sim = oracle.loop_test(int(s["good_count"]), int(fs.counts[c]) + c % 3, int(fs.counts[i]) + i % 3, p)
+                    if ok:
+                        want.append((int(fs.ids[c]), int(fs.ids[i]), int(s["good_count"]), sim))
+        assert len(want) > 0
+        assert [(int(r["current_frame_id"]), int(r["matched_frame_id"]), int(r["num_matches"]), float(r["similarity_score"]))
+                for r in got] == want
+        with pytest.raises(pkg.LcmError) as e:
+            matcher.all_vs_all_loops(cap=1)
+        assert e.value.code == -4
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
