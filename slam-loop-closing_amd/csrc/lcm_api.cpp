@@ -106,6 +106,8 @@ struct lcm_handle {
     int32_t* d_tcounts = nullptr; size_t d_tcounts_n = 0;
     uint32_t* d_keys = nullptr; size_t d_keys_n = 0;
     lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
+    lcm_score* d_scores2 = nullptr; size_t d_scores2_n = 0;
+    int32_t* d_chunk_counts = nullptr; size_t d_chunk_counts_n = 0;
     lcm::WorkItem* d_items = nullptr; size_t d_items_n = 0;
     std::vector<lcm_score> h_scores;
     std::vector<uint32_t> h_keys;
@@ -332,6 +334,7 @@ void lcm_destroy(lcm_handle* h) {
     (void)hipFree(h->d_qbuf); (void)hipFree(h->d_qcounts); (void)hipFree(h->d_tbuf); (void)hipFree(h->d_tcounts);
     (void)hipFree(h->d_keys); (void)hipFree(h->d_scores); (void)hipFree(h->d_items); (void)hipFree(h->plan.d_items);
     (void)hipFree(h->d_bulk_scores); (void)hipFree(h->d_meta); (void)hipFree(h->d_cands);
+    (void)hipFree(h->d_scores2); (void)hipFree(h->d_chunk_counts);
     for (int i = 0; i < STAGE_BUFS; ++i) {
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
@@ -668,10 +671,68 @@ int lcm_loop_test(const lcm_params* p, const lcm_score* s, int n_query_kp, int n
 }
 
 // scores of (query frame at q_rows[q_frame]) against stored slots [0, n_elig)
+static void account_prefix(lcm_handle* h, int nq, int n_elig) {
+    uint64_t dist = 0, bytes = (uint64_t)nq * 32;
+    for (int s = 0; s < n_elig; ++s) { dist += (uint64_t)nq * h->frames[s].n; bytes += (uint64_t)h->frames[s].n * 32 + 8; }
+    h->info.pairs = (uint64_t)n_elig; h->info.distances = dist; h->info.algo_bytes = bytes;
+}
+
+// Short database: fewer pairs than the chip has room for workgroups.  Cut every pair's query rows into chunks so that
+// 2 / 4 / 8 workgroups share a pair (lcm_kernels.hip, "Split mode"), then fold per pair on the device.
+static int score_prefix_split(lcm_handle* h, const uint32_t* q_frame_rows, int nq, int n_elig, int qpt, lcm_score* out_scores) {
+    const int chunk_rows = 256 * qpt;
+    const int n_chunks = (nq + chunk_rows - 1) / chunk_rows;
+    const size_t n_items = (size_t)n_elig * n_chunks;
+    std::vector<int32_t> qc(n_chunks);
+    std::vector<lcm::WorkItem> items(n_items);
+    for (int c = 0; c < n_chunks; ++c) qc[c] = std::min(chunk_rows, nq - c * chunk_rows);
+    for (int s = 0; s < n_elig; ++s)
+        for (int c = 0; c < n_chunks; ++c)
+            items[(size_t)s * n_chunks + c] = {(uint32_t)c, (uint32_t)s, 1u, (uint32_t)(s * n_chunks + c)};
+    int rc = ensure_dev(h->d_items, h->d_items_n, n_items); if (rc) return rc;
+    rc = ensure_dev(h->d_scores, h->d_scores_n, std::max<size_t>(n_items, (size_t)n_elig)); if (rc) return rc;
+    rc = ensure_dev(h->d_scores2, h->d_scores2_n, (size_t)n_elig); if (rc) return rc;
+    rc = ensure_dev(h->d_keys, h->d_keys_n, n_items * chunk_rows); if (rc) return rc;
+    rc = ensure_dev(h->d_chunk_counts, h->d_chunk_counts_n, (size_t)n_chunks); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_items, items.data(), sizeof(lcm::WorkItem) * n_items, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_chunk_counts, qc.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, h->stream));
+    lcm::ScoreArgs a{};
+    a.q_rows = q_frame_rows; a.q_counts = h->d_chunk_counts; a.q_stride_words = (uint32_t)chunk_rows * LCM_DESC_WORDS;
+    a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
+    a.items = h->d_items; a.scores = h->d_scores /* per-chunk partial records: unused */; a.keys = h->d_keys; a.keys_stride = (uint32_t)chunk_rows;
+    a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    hipError_t e = lcm::launch_score_split(a, (uint32_t)n_items, qpt, h->stream);
+    if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    lcm::FinalizeArgs f{};
+    f.dist = h->d_keys; f.padded_rows = (uint32_t)(n_chunks * chunk_rows); f.nq = nq;
+    f.db_counts = h->d_counts; f.slot_begin = 0; f.scores = h->d_scores2;
+    f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
+    e = lcm::launch_finalize(f, (uint32_t)n_elig, h->stream);
+    if (e != hipSuccess) return fail(LCM_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    h->info_pending = true; h->info.launches = 2; h->info.workgroups = (uint32_t)n_items;
+    account_prefix(h, nq, n_elig);
+    HIP_TRY(hipMemcpyAsync(out_scores, h->d_scores2, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return LCM_OK;
+}
+
+// scores of (query frame at q_rows[q_frame]) against stored slots [0, n_elig)
 static int score_prefix(lcm_handle* h, const uint32_t* q_rows, const int32_t* q_counts, uint32_t q_stride_words,
                         uint32_t q_frame, int nq, int n_elig, lcm_score* out_scores) {
     if (n_elig <= 0) return LCM_OK;
     int rc = wait_db(h); if (rc) return rc;
+    static const int split_env = [] { const char* e = getenv("LCM_SPLIT"); return e ? atoi(e) : -1; }();   // tuning knob
+    int qpt = 0;
+    if (h->variant == 0 && nq > 512) {
+        if (split_env >= 0) qpt = split_env;                 // 0 = never split, 1/2/4 = force that many rows per lane
+        else if (n_elig < 160) qpt = 1;
+        else if (n_elig < 320) qpt = 2;
+        else if (n_elig < 640) qpt = 4;
+    }
+    if (qpt == 1 || qpt == 2 || qpt == 4)
+        return score_prefix_split(h, q_rows + (size_t)q_frame * q_stride_words, nq, n_elig, qpt, out_scores);
     const int chunk = n_elig >= 8192 ? 4 : (n_elig >= 4096 ? 2 : 1);
     const int n_items = (n_elig + chunk - 1) / chunk;
     std::vector<lcm::WorkItem> items(n_items);
@@ -688,9 +749,7 @@ static int score_prefix(lcm_handle* h, const uint32_t* q_rows, const int32_t* q_
     a.items = h->d_items; a.scores = h->d_scores; a.keys = nullptr; a.keys_stride = 0;
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
     rc = launch_and_time(h, a, (uint32_t)n_items, nq, false); if (rc) return rc;
-    uint64_t dist = 0, bytes = (uint64_t)nq * 32;
-    for (int s = 0; s < n_elig; ++s) { dist += (uint64_t)nq * h->frames[s].n; bytes += (uint64_t)h->frames[s].n * 32 + 8; }
-    h->info.pairs = (uint64_t)n_elig; h->info.distances = dist; h->info.algo_bytes = bytes;
+    account_prefix(h, nq, n_elig);
     HIP_TRY(hipMemcpyAsync(out_scores, h->d_scores, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return LCM_OK;

@@ -38,6 +38,20 @@ struct ScoreArgs {
 hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
                         hipStream_t st);
 
+// Split mode (short databases): chunks of 256 * qpt query rows per workgroup write per-row best distances into
+// a.keys; launch_finalize folds each pair's rows into its lcm_score record.
+hipError_t launch_score_split(const ScoreArgs& a, uint32_t n_items, int qpt, hipStream_t st);
+struct FinalizeArgs {
+    const uint32_t* dist;        // best distance per (pair, row): dist[pair * padded_rows + row]
+    uint32_t        padded_rows;
+    int32_t         nq;          // real query rows
+    const int32_t*  db_counts;   // stored row counts; pair p is slot slot_begin + p
+    uint32_t        slot_begin;
+    void*           scores;      // lcm_score per pair
+    int32_t         ratio, dist_floor;
+};
+hipError_t launch_finalize(const FinalizeArgs& a, uint32_t n_pairs, hipStream_t st);
+
 // On-device loop test over a finished score array (BASELINE.json configs[3] "fused on-device filter + loop test"):
 // pair p belongs to query frame c = upper_bound(offsets, p) - 1 and stored slot p - offsets[c]; a candidate is
 // similarity = good / min(kp_q, kp_t) > sim_threshold (IEEE double, strict) and good >= min_matches.  Candidates

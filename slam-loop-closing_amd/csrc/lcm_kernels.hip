@@ -109,7 +109,7 @@ __device__ __forceinline__ void fold2_min(uint32_t& best, const uint32_t (&q)[8]
 // ---------------------------------------------------------------------------------------------------
 template <int THREADS, int QPT, bool ARGMIN, bool WRITE_KEYS>
 __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
-    static_assert(ARGMIN || !WRITE_KEYS, "keys need the argmin path");
+    // ARGMIN = false with WRITE_KEYS = true writes the best DISTANCE per query row (split mode, see k_finalize_pairs)
     constexpr int DSHIFT = ARGMIN ? KEY_SHIFT : 0;      // best[j] >> DSHIFT is the best distance
     __shared__ uint32_t red_min[2];
     __shared__ uint32_t red_sum[2];
@@ -379,14 +379,65 @@ static unsigned lds_pad_bytes() {
 template <int THREADS, int QPT>
 static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool write_keys, bool argmin, hipStream_t st) {
     if (n_items == 0) return hipSuccess;
-    const unsigned lds = THREADS == 256 ? lds_pad_bytes() : 0;
-    if (write_keys)
+    const unsigned lds = (THREADS == 256 && QPT == 8) ? lds_pad_bytes() : 0;
+    if (write_keys && argmin)
         hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true, true>), dim3(n_items), dim3(THREADS), lds, st, a);
+    else if (write_keys)
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, false, true>), dim3(n_items), dim3(THREADS), lds, st, a);
     else if (argmin)
         hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true, false>), dim3(n_items), dim3(THREADS), lds, st, a);
     else
         hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, false, false>), dim3(n_items), dim3(THREADS), lds, st, a);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Split mode for SHORT databases (online queries against fewer than ~1000 stored frames): one workgroup per pair
+// leaves the chip under-filled, so a pair's query rows are cut into chunks of 256 * QPT rows (QPT = 4, 2 or 1 rows per
+// lane -> 2, 4 or 8 workgroups per pair), every chunk writes its rows' best distances, and this kernel — one
+// workgroup per pair — folds them into the usual score record (min-of-mins, ratio filter, count).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize_pairs(FinalizeArgs a) {
+    __shared__ uint32_t red_min, red_sum;
+    const int tid = threadIdx.x;
+    const uint32_t pair = blockIdx.x;
+    if (tid == 0) { red_min = 0xFFFFFFFFu; red_sum = 0u; }
+    __syncthreads();
+    const uint32_t* d = a.dist + (size_t)pair * a.padded_rows;
+    uint32_t dmin = 0xFFFFFFFFu;
+    for (int r = tid; r < a.nq; r += 256) dmin = min(dmin, d[r]);
+    atomicMin(&red_min, dmin);
+    __syncthreads();
+    dmin = red_min;
+    const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
+    uint32_t cnt = 0;
+    for (int r = tid; r < a.nq; r += 256) cnt += d[r] <= thr ? 1u : 0u;
+    atomicAdd(&red_sum, cnt);
+    __syncthreads();
+    if (tid == 0) {
+        const int nt = a.db_counts[a.slot_begin + pair];
+        const bool empty = (a.nq <= 0) || (nt <= 0);
+        uint2 rec;
+        rec.x = empty ? 0u : red_sum;
+        rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
+        reinterpret_cast<uint2*>(a.scores)[pair] = rec;
+    }
+}
+
+hipError_t launch_finalize(const FinalizeArgs& a, uint32_t n_pairs, hipStream_t st) {
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize_pairs, dim3(n_pairs), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// Split-mode launch: 256-thread workgroups holding `qpt` query rows per lane, writing best distances to a.keys.
+hipError_t launch_score_split(const ScoreArgs& a, uint32_t n_items, int qpt, hipStream_t st) {
+    switch (qpt) {
+        case 4: return launch_rowlane<256, 4>(a, n_items, true, false, st);
+        case 2: return launch_rowlane<256, 2>(a, n_items, true, false, st);
+        case 1: return launch_rowlane<256, 1>(a, n_items, true, false, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

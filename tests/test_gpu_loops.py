@@ -291,3 +291,31 @@ def test_fused_on_device_loop_test(matcher, oracle, pkg):
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+def test_short_database_split_mode_all_regimes(matcher, oracle, pkg):
+    """lcm_query_scores cuts a pair's query rows over 8 / 4 / 2 / 1 workgroups depending on how many stored frames are
+    eligible (< 160 / < 320 / < 640 / more).  Every regime must give the single-workgroup answer."""
+    fs = pkg.synth.make_frames(700, 600, seed=57, ragged=True, dup_frac=0.2)
+    fs.counts[50] = 0
+    gap = 1
+    matcher.set_params(min_gap=gap)
+    try:
+        fill(matcher, fs)
+        p = oracle.default_params(min_gap=gap)
+        for cur in (100, 159, 161, 250, 500, 699):
+            scores, ids = matcher.query_scores(fs.frame(cur), int(fs.ids[cur]))
+            assert len(scores) == cur                                   # ids == positions, gap 1
+            want, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, [cur] * cur, list(range(cur)), p, n_threads=8)
+            np.testing.assert_array_equal(scores, want)
+            cands = matcher.detect_loops(int(fs.ids[cur]))              # stored-frame query through the same path
+            keep = [i for i in range(cur) if oracle.loop_test(int(want[i]["good_count"]), int(fs.counts[cur]), int(fs.counts[i]), p)[0]]
+            assert cands["matched_frame_id"].tolist() == [int(fs.ids[i]) for i in keep]
+        # an empty query frame through the split path's guard (nq <= 512 never splits) and a full-size one
+        big = pkg.synth.make_frames(4, 2000, seed=3)
+        scores, _ = matcher.query_scores(big.frame(0), 120)
+        want = [oracle.pair_score(big.frame(0), fs.frame(i), p) for i in (0, 50, 119)]
+        assert [scores[0], scores[50], scores[119]] == want
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
