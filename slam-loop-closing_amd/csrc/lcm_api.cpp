@@ -852,6 +852,7 @@ int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_que
     if (key == 0) key = 1;
     Plan& P = h->plan;
     if (P.key != key) {
+        P.key = 0;                        // a failed rebuild must not leave a half-built plan behind the old key
         P.items.clear();
         P.offsets.assign((size_t)n_q_frames + 1, 0);
         size_t total = 0;
