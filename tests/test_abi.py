@@ -78,3 +78,42 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(d, f), errors="replace").read()
                 assert "lcm_oracle" not in txt and "oracle/" not in txt.replace("oracle/ is", "").replace("under oracle/", ""), \
                     f"{f} refers to the oracle"
+
+
+def test_null_handle_calls_fail_cleanly(pkg):
+    """Every entry point must reject a NULL handle with a status code (never crash), GPU or not."""
+    import ctypes as C
+    lib = pkg.load_library()
+    n = C.c_int32(0)
+    z = C.c_size_t(0)
+    info = pkg.capi.LaunchInfo()
+    p = pkg.default_params()
+    buf = (C.c_uint8 * 64)()
+    assert lib.lcm_set_params(None, C.byref(p)) == -1
+    assert lib.lcm_get_params(None, C.byref(p)) == -1
+    assert lib.lcm_sync(None) == -1
+    assert lib.lcm_db_reserve(None, 1, 1) == -1
+    assert lib.lcm_db_append(None, 0, buf, 1, -1) == -1
+    assert lib.lcm_db_append_device(None, 0, buf, 1, -1) == -1
+    assert lib.lcm_db_size(None) == 0
+    assert lib.lcm_db_clear(None) == -1
+    assert lib.lcm_db_frame_info(None, 0, None, None, None) == -1
+    assert lib.lcm_db_read(None, 0, buf, 1) == -1
+    assert lib.lcm_db_save(None, b"/tmp/x") == -1
+    assert lib.lcm_db_load(None, b"/tmp/x") == -1
+    assert lib.lcm_match_pair(None, buf, 1, buf, 1, buf, buf, C.byref(n)) == -1
+    assert lib.lcm_match_features(None, buf, 1, buf, 1, buf, C.byref(n), C.byref(n)) == -1
+    assert lib.lcm_match_stored(None, 0, 1, buf, 1, C.byref(n), C.byref(n)) == -1
+    assert lib.lcm_query_scores(None, buf, 1, 0, buf, buf, C.byref(n)) == -1
+    assert lib.lcm_detect_loops(None, 0, buf, 1, 1, buf, 1, C.byref(n)) == -1
+    assert lib.lcm_all_vs_all(None, None, None, None, 0, 0, None, 0, C.byref(z), None) == -1
+    assert lib.lcm_all_vs_all_loops(None, None, None, None, None, 0, 0, None, 0, C.byref(z), C.byref(z)) == -1
+    assert lib.lcm_last_launch_info(None, C.byref(info)) == -1
+    assert lib.lcm_set_kernel_variant(None, 0) == -1
+    assert lib.lcm_dev_alloc(None, 16, C.byref(C.c_void_p())) == -1
+    assert lib.lcm_dev_free(None, None) == -1
+    assert lib.lcm_dev_upload(None, None, None, 0) == -1
+    assert lib.lcm_dev_download(None, None, None, 0) == -1
+    lib.lcm_destroy(None)                                   # no-op
+    assert b"" != lib.lcm_last_error()
+    assert lib.lcm_create(C.byref(p), 0, None, None) == -1  # out == NULL
