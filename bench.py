@@ -56,9 +56,10 @@ def host_cores():
 
 
 def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi, wl_desc, seed):
-    """Online mode: frames arrive one at a time as HOST rows.  Per frame: lcm_query_scores (H2D of the 64 KB query,
-    kernel over this rank's shard, D2H of the 8-byte records) and, if this rank owns the frame's position,
-    lcm_db_append (pinned staging + hipMemcpyAsync on the copy stream, overlapping the next frame's scoring).
+    """Online mode: frames arrive one at a time as HOST rows.  Per frame: lcm_query_submit (pinned staging, H2D of the
+    64 KB query, kernel over this rank's shard, D2H of the 8-byte records — all enqueued, no host wait), then, if this
+    rank owns the frame's position, lcm_db_append (pinned staging + hipMemcpyAsync on the copy stream), then
+    lcm_query_collect of the PREVIOUS frame: one query is always in flight while the host prepares the next.
     One step = one pass over the whole sequence.  Scores are gathered once per step (RCCL) when N > 1."""
     p = pkg.default_params()
     p.min_gap = args.gap
@@ -73,12 +74,23 @@ def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi,
     def one_pass():
         m.clear()
         out, dist_n = [], 0
-        for f in range(n_frames):
-            sc, _ = m.query_scores(frames[f], int(fs.ids[f]))
+
+        def take(ticket, f):
+            nonlocal dist_n
+            sc, _ = m.query_collect(ticket)
             out.append(sc)
             dist_n += int(sc["n_train"].astype(np.int64).sum()) * frames[f].shape[0]
+
+        prev = None
+        for f in range(n_frames):
+            t = m.query_submit(frames[f], int(fs.ids[f]))        # enqueued; the host moves on
             if f % world == rank:
-                m.append(int(fs.ids[f]), frames[f])
+                m.append(int(fs.ids[f]), frames[f])              # copy stream: overlaps the query just submitted
+            if prev is not None:
+                take(*prev)                                      # results of the PREVIOUS frame
+            prev = (t, f)
+        if prev is not None:
+            take(*prev)
         m.sync()
         local = np.concatenate(out) if out else np.zeros(0, pkg.capi.SCORE_DTYPE)
         if multi:

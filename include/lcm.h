@@ -163,6 +163,12 @@ LCM_API int  lcm_match_stored(lcm_handle* h, int query_frame_id, int train_frame
  * slot order.  out_scores / out_frame_ids need room for lcm_db_size() records. */
 LCM_API int  lcm_query_scores(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id,
                               lcm_score* out_scores, int32_t* out_frame_ids, int* n_out);
+/* The same query, asynchronously (streaming mode): lcm_query_submit copies `query` into pinned staging, enqueues the
+ * upload, the kernel(s) and the download of the records, and returns a ticket without waiting; up to 4 queries may be
+ * in flight.  lcm_query_collect waits for that ticket and copies the records out (cap = room in out_scores /
+ * out_frame_ids).  Frames appended after the submit are not part of its answer. */
+LCM_API int  lcm_query_submit(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, int* ticket);
+LCM_API int  lcm_query_collect(lcm_handle* h, int ticket, lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out);
 /* detectLoops for a frame that is already stored (or given explicitly with query != NULL). */
 LCM_API int  lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
                               lcm_loop_candidate* out, int cap, int* n_out);

@@ -85,6 +85,8 @@ _SIGNATURES = {
     "lcm_match_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _i32p, _i32p]),
     "lcm_match_stored": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _i32p, _i32p]),
     "lcm_query_scores": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _i32p]),
+    "lcm_query_submit": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i32p]),
+    "lcm_query_collect": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i32p]),
     "lcm_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
     "lcm_loop_test": (C.c_int, [C.POINTER(Params), C.POINTER(Score), C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lcm_all_vs_all": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
@@ -258,6 +260,22 @@ class Matcher:
         n = C.c_int32(0)
         _check(self._lib.lcm_query_scores(self._h, _ptr(q), q.shape[0], query_frame_id, scores.ctypes.data_as(_vp),
                                           ids.ctypes.data_as(_vp), C.byref(n)))
+        return scores[: n.value], ids[: n.value]
+
+    def query_submit(self, query, query_frame_id: int) -> int:
+        """Asynchronous query: returns a ticket at once (the rows are copied before returning)."""
+        q = _rows(query)
+        t = C.c_int32(-1)
+        _check(self._lib.lcm_query_submit(self._h, _ptr(q), q.shape[0], query_frame_id, C.byref(t)))
+        return t.value
+
+    def query_collect(self, ticket: int) -> Tuple[np.ndarray, np.ndarray]:
+        cap = max(len(self), 1)
+        scores = np.zeros(cap, SCORE_DTYPE)
+        ids = np.zeros(cap, np.int32)
+        n = C.c_int32(0)
+        _check(self._lib.lcm_query_collect(self._h, ticket, scores.ctypes.data_as(_vp), ids.ctypes.data_as(_vp), cap,
+                                           C.byref(n)))
         return scores[: n.value], ids[: n.value]
 
     def detect_loops(self, current_frame_id: int, query=None, n_keypoints: int = -1) -> np.ndarray:

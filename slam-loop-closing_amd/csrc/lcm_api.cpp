@@ -56,6 +56,20 @@ struct FrameMeta {
     int32_t n_kp;    // keypoints (similarity denominator)
 };
 
+constexpr int QUERY_SLOTS = 4;    // online queries that may be in flight at once (lcm_query_submit / _collect)
+
+struct QuerySlot {                // everything one in-flight online query owns
+    bool busy = false;
+    int n_elig = 0, nq = 0, query_id = 0;
+    uint8_t* h_query = nullptr;   size_t h_query_bytes = 0;    // pinned staging of the query rows
+    lcm_score* h_scores = nullptr; size_t h_scores_n = 0;      // pinned landing zone of the score records
+    uint8_t* d_query = nullptr;   size_t d_query_bytes = 0;
+    lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
+    lcm_score* d_partial = nullptr; size_t d_partial_n = 0;    // split mode: per-chunk partial records (unused)
+    uint32_t* d_dist = nullptr;   size_t d_dist_n = 0;         // split mode: best distance per (pair, row)
+    hipEvent_t done = nullptr;
+};
+
 struct Plan {            // cached work list of one bulk call shape
     uint64_t key = 0;    // hash of what it was built from
     std::vector<lcm::WorkItem> items;
@@ -106,15 +120,13 @@ struct lcm_handle {
     int32_t* d_tcounts = nullptr; size_t d_tcounts_n = 0;
     uint32_t* d_keys = nullptr; size_t d_keys_n = 0;
     lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
-    lcm_score* d_scores2 = nullptr; size_t d_scores2_n = 0;
-    int32_t* d_chunk_counts = nullptr; size_t d_chunk_counts_n = 0;
     lcm::WorkItem* d_items = nullptr; size_t d_items_n = 0;
-    std::vector<lcm_score> h_scores;
     std::vector<uint32_t> h_keys;
     lcm_score* d_bulk_scores = nullptr; size_t d_bulk_scores_n = 0;   // lcm_all_vs_all_loops: scores stay on the device
     int32_t* d_meta = nullptr; size_t d_meta_n = 0;
     lcm_loop_candidate* d_cands = nullptr; size_t d_cands_n = 0;
 
+    QuerySlot qslots[QUERY_SLOTS];
     Plan plan;
     lcm_launch_info info{};
     bool info_pending = false;
@@ -134,6 +146,17 @@ int ensure_dev(T*& p, size_t& have, size_t need, size_t slack_bytes = 0) {
     p = nullptr; have = 0;
     size_t n = std::max<size_t>(need, 16);
     HIP_TRY(hipMalloc((void**)&p, n * sizeof(T) + slack_bytes));
+    have = n;
+    return LCM_OK;
+}
+
+template <typename T>
+int ensure_pinned(T*& p, size_t& have, size_t need) {
+    if (need <= have && p) return LCM_OK;
+    if (p) HIP_TRY(hipHostFree(p));
+    p = nullptr; have = 0;
+    const size_t n = std::max<size_t>(need, 16);
+    HIP_TRY(hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault));
     have = n;
     return LCM_OK;
 }
@@ -334,7 +357,12 @@ void lcm_destroy(lcm_handle* h) {
     (void)hipFree(h->d_qbuf); (void)hipFree(h->d_qcounts); (void)hipFree(h->d_tbuf); (void)hipFree(h->d_tcounts);
     (void)hipFree(h->d_keys); (void)hipFree(h->d_scores); (void)hipFree(h->d_items); (void)hipFree(h->plan.d_items);
     (void)hipFree(h->d_bulk_scores); (void)hipFree(h->d_meta); (void)hipFree(h->d_cands);
-    (void)hipFree(h->d_scores2); (void)hipFree(h->d_chunk_counts);
+    for (QuerySlot& q : h->qslots) {
+        (void)hipFree(q.d_query); (void)hipFree(q.d_scores); (void)hipFree(q.d_partial); (void)hipFree(q.d_dist);
+        if (q.h_query) (void)hipHostFree(q.h_query);
+        if (q.h_scores) (void)hipHostFree(q.h_scores);
+        if (q.done) (void)hipEventDestroy(q.done);
+    }
     for (int i = 0; i < STAGE_BUFS; ++i) {
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
@@ -677,101 +705,131 @@ static void account_prefix(lcm_handle* h, int nq, int n_elig) {
     h->info.pairs = (uint64_t)n_elig; h->info.distances = dist; h->info.algo_bytes = bytes;
 }
 
-// Short database: fewer pairs than the chip has room for workgroups.  Cut every pair's query rows into chunks so that
-// 2 / 4 / 8 workgroups share a pair (lcm_kernels.hip, "Split mode"), then fold per pair on the device.
-static int score_prefix_split(lcm_handle* h, const uint32_t* q_frame_rows, int nq, int n_elig, int qpt, lcm_score* out_scores) {
-    const int chunk_rows = 256 * qpt;
-    const int n_chunks = (nq + chunk_rows - 1) / chunk_rows;
-    const size_t n_items = (size_t)n_elig * n_chunks;
-    std::vector<int32_t> qc(n_chunks);
-    std::vector<lcm::WorkItem> items(n_items);
-    for (int c = 0; c < n_chunks; ++c) qc[c] = std::min(chunk_rows, nq - c * chunk_rows);
-    for (int s = 0; s < n_elig; ++s)
-        for (int c = 0; c < n_chunks; ++c)
-            items[(size_t)s * n_chunks + c] = {(uint32_t)c, (uint32_t)s, 1u, (uint32_t)(s * n_chunks + c)};
-    int rc = ensure_dev(h->d_items, h->d_items_n, n_items); if (rc) return rc;
-    rc = ensure_dev(h->d_scores, h->d_scores_n, std::max<size_t>(n_items, (size_t)n_elig)); if (rc) return rc;
-    rc = ensure_dev(h->d_scores2, h->d_scores2_n, (size_t)n_elig); if (rc) return rc;
-    rc = ensure_dev(h->d_keys, h->d_keys_n, n_items * chunk_rows); if (rc) return rc;
-    rc = ensure_dev(h->d_chunk_counts, h->d_chunk_counts_n, (size_t)n_chunks); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h->d_items, items.data(), sizeof(lcm::WorkItem) * n_items, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_chunk_counts, qc.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, h->stream));
-    lcm::ScoreArgs a{};
-    a.q_rows = q_frame_rows; a.q_counts = h->d_chunk_counts; a.q_stride_words = (uint32_t)chunk_rows * LCM_DESC_WORDS;
-    a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
-    a.items = h->d_items; a.scores = h->d_scores /* per-chunk partial records: unused */; a.keys = h->d_keys; a.keys_stride = (uint32_t)chunk_rows;
-    a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
-    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-    hipError_t e = lcm::launch_score_split(a, (uint32_t)n_items, qpt, h->stream);
-    if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-    lcm::FinalizeArgs f{};
-    f.dist = h->d_keys; f.padded_rows = (uint32_t)(n_chunks * chunk_rows); f.nq = nq;
-    f.db_counts = h->d_counts; f.slot_begin = 0; f.scores = h->d_scores2;
-    f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
-    e = lcm::launch_finalize(f, (uint32_t)n_elig, h->stream);
-    if (e != hipSuccess) return fail(LCM_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
-    h->info_pending = true; h->info.launches = 2; h->info.workgroups = (uint32_t)n_items;
-    account_prefix(h, nq, n_elig);
-    HIP_TRY(hipMemcpyAsync(out_scores, h->d_scores2, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return LCM_OK;
-}
-
-// scores of (query frame at q_rows[q_frame]) against stored slots [0, n_elig)
-static int score_prefix(lcm_handle* h, const uint32_t* q_rows, const int32_t* q_counts, uint32_t q_stride_words,
-                        uint32_t q_frame, int nq, int n_elig, lcm_score* out_scores) {
-    if (n_elig <= 0) return LCM_OK;
+// Enqueue (no host synchronisation) the scoring of ONE query frame — `nq` rows at device address d_q — against stored
+// slots [0, n_elig), and the download of the n_elig score records into the slot's pinned buffer.  Work items are
+// implicit (derived from blockIdx), so nothing but the query itself crosses PCIe.  Short databases use the split
+// mode (lcm_kernels.hip): 2 / 4 / 8 workgroups per pair + the on-device fold.
+static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int nq, int n_elig) {
+    q.n_elig = n_elig; q.nq = nq;
+    if (n_elig <= 0) { HIP_TRY(hipEventRecord(q.done, h->stream)); return LCM_OK; }
     int rc = wait_db(h); if (rc) return rc;
     static const int split_env = [] { const char* e = getenv("LCM_SPLIT"); return e ? atoi(e) : -1; }();   // tuning knob
     int qpt = 0;
     if (h->variant == 0 && nq > 512) {
         if (split_env >= 0) qpt = split_env;                 // 0 = never split, 1/2/4 = force that many rows per lane
-        else if (n_elig < 160) qpt = 1;
-        else if (n_elig < 320) qpt = 2;
-        else if (n_elig < 640) qpt = 4;
+        // measured (bench.py --mode stream, LCM_SPLIT sweep): finer pieces balance 256 CUs better whenever a launch
+        // holds only a few thousand pairs — 1000 frames: 1.71e12 unsplit -> 2.18e12; 2500 frames: 2.32e12 -> 2.57e12
+        else if (n_elig < 256) qpt = 1;
+        else if (n_elig < 3072) qpt = 2;
+        else if (n_elig < 6144) qpt = 4;
     }
-    if (qpt == 1 || qpt == 2 || qpt == 4)
-        return score_prefix_split(h, q_rows + (size_t)q_frame * q_stride_words, nq, n_elig, qpt, out_scores);
-    const int chunk = n_elig >= 8192 ? 4 : (n_elig >= 4096 ? 2 : 1);
-    const int n_items = (n_elig + chunk - 1) / chunk;
-    std::vector<lcm::WorkItem> items(n_items);
-    for (int i = 0; i < n_items; ++i) {
-        uint32_t b = (uint32_t)i * chunk;
-        items[i] = {q_frame, b, (uint32_t)std::min(chunk, n_elig - (int)b), b};
-    }
-    rc = ensure_dev(h->d_items, h->d_items_n, (size_t)n_items); if (rc) return rc;
-    rc = ensure_dev(h->d_scores, h->d_scores_n, (size_t)n_elig); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h->d_items, items.data(), sizeof(lcm::WorkItem) * n_items, hipMemcpyHostToDevice, h->stream));
+    rc = ensure_dev(q.d_scores, q.d_scores_n, (size_t)n_elig); if (rc) return rc;
+    rc = ensure_pinned(q.h_scores, q.h_scores_n, (size_t)n_elig); if (rc) return rc;
     lcm::ScoreArgs a{};
-    a.q_rows = q_rows; a.q_counts = q_counts; a.q_stride_words = q_stride_words;
+    a.q_rows = d_q; a.q_counts = nullptr; a.items = nullptr;
     a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
-    a.items = h->d_items; a.scores = h->d_scores; a.keys = nullptr; a.keys_stride = 0;
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
-    rc = launch_and_time(h, a, (uint32_t)n_items, nq, false); if (rc) return rc;
+    a.imp_nq = nq; a.imp_total = (uint32_t)n_elig;
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    if (qpt == 1 || qpt == 2 || qpt == 4) {
+        const int chunk_rows = 256 * qpt;
+        const int n_chunks = (nq + chunk_rows - 1) / chunk_rows;
+        const size_t n_items = (size_t)n_elig * n_chunks;
+        rc = ensure_dev(q.d_partial, q.d_partial_n, n_items); if (rc) return rc;
+        rc = ensure_dev(q.d_dist, q.d_dist_n, n_items * chunk_rows); if (rc) return rc;
+        a.q_stride_words = (uint32_t)chunk_rows * LCM_DESC_WORDS;
+        a.imp_chunks = (uint32_t)n_chunks; a.imp_chunk_rows = (uint32_t)chunk_rows; a.imp_spi = 1;
+        a.scores = q.d_partial /* per-chunk partial records: unused */; a.keys = q.d_dist; a.keys_stride = (uint32_t)chunk_rows;
+        hipError_t e = lcm::launch_score_split(a, (uint32_t)n_items, qpt, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        lcm::FinalizeArgs f{};
+        f.dist = q.d_dist; f.padded_rows = (uint32_t)(n_chunks * chunk_rows); f.nq = nq;
+        f.db_counts = h->d_counts; f.slot_begin = 0; f.scores = q.d_scores;
+        f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
+        e = lcm::launch_finalize(f, (uint32_t)n_elig, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
+        h->info.launches = 2; h->info.workgroups = (uint32_t)n_items;
+    } else {
+        const int spi = n_elig >= 8192 ? 4 : (n_elig >= 4096 ? 2 : 1);
+        const uint32_t n_items = (uint32_t)((n_elig + spi - 1) / spi);
+        a.q_stride_words = 0;
+        a.imp_chunks = 1; a.imp_chunk_rows = (uint32_t)std::max(nq, 1); a.imp_spi = (uint32_t)spi;
+        a.scores = q.d_scores; a.keys = nullptr; a.keys_stride = 0;
+        hipError_t e = lcm::launch_score(a, n_items, nq, false, h->variant, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        h->info.launches = 1; h->info.workgroups = n_items;
+    }
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    h->info_pending = true;
     account_prefix(h, nq, n_elig);
-    HIP_TRY(hipMemcpyAsync(out_scores, h->d_scores, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(q.done, h->stream));
+    return LCM_OK;
+}
+
+static int find_slot(const lcm_handle* h, int frame_id) {
+    int lo = 0, hi = (int)h->frames.size();
+    while (lo < hi) { int mid = (lo + hi) / 2; if (h->frames[mid].id < frame_id) lo = mid + 1; else hi = mid; }
+    return (lo < (int)h->frames.size() && h->frames[lo].id == frame_id) ? lo : -1;
+}
+
+static int acquire_query_slot(lcm_handle* h, int* ticket) {
+    for (int i = 0; i < QUERY_SLOTS; ++i)
+        if (!h->qslots[i].busy) {
+            if (!h->qslots[i].done) HIP_TRY(hipEventCreateWithFlags(&h->qslots[i].done, hipEventDisableTiming));
+            *ticket = i;
+            return LCM_OK;
+        }
+    return fail(LCM_ERR_CAPACITY, "%d queries already in flight: collect one first", QUERY_SLOTS);
+}
+
+int lcm_query_submit(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, int* ticket) {
+    if (!h || nq < 0 || !ticket || (nq > 0 && !query)) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    *ticket = -1;
+    if (nq > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+    int rc = set_device(h); if (rc) return rc;
+    int t = -1;
+    rc = acquire_query_slot(h, &t); if (rc) return rc;
+    QuerySlot& q = h->qslots[t];
+    q.query_id = query_frame_id;
+    const int n_elig = eligible_prefix(h, query_frame_id, h->params.min_gap);
+    const size_t bytes = (size_t)std::max(nq, 1) * LCM_DESC_BYTES;
+    rc = ensure_pinned(q.h_query, q.h_query_bytes, bytes); if (rc) return rc;
+    rc = ensure_dev(q.d_query, q.d_query_bytes, bytes, ARENA_SLACK); if (rc) return rc;
+    if (nq > 0 && n_elig > 0) {
+        memcpy(q.h_query, query, (size_t)nq * LCM_DESC_BYTES);       // the caller's buffer is free when we return
+        HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, (size_t)nq * LCM_DESC_BYTES, hipMemcpyHostToDevice, h->stream));
+    }
+    rc = enqueue_query(h, q, (const uint32_t*)q.d_query, nq, n_elig); if (rc) return rc;
+    q.busy = true;
+    *ticket = t;
+    return LCM_OK;
+}
+
+int lcm_query_collect(lcm_handle* h, int ticket, lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out) {
+    if (!h || !n_out || ticket < 0 || ticket >= QUERY_SLOTS || !h->qslots[ticket].busy) return fail(LCM_ERR_INVALID_ARG, "bad ticket");
+    *n_out = 0;
+    int rc = set_device(h); if (rc) return rc;
+    QuerySlot& q = h->qslots[ticket];
+    HIP_TRY(hipEventSynchronize(q.done));
+    q.busy = false;
+    if (q.n_elig > cap) return fail(LCM_ERR_CAPACITY, "%d score records but room for %d", q.n_elig, cap);
+    if (q.n_elig > 0) {
+        if (!out_scores) return fail(LCM_ERR_INVALID_ARG, "out_scores is NULL");
+        memcpy(out_scores, q.h_scores, sizeof(lcm_score) * (size_t)q.n_elig);
+        if (out_frame_ids) for (int s = 0; s < q.n_elig; ++s) out_frame_ids[s] = h->frames[s].id;
+    }
+    *n_out = q.n_elig;
     return LCM_OK;
 }
 
 int lcm_query_scores(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id,
                      lcm_score* out_scores, int32_t* out_frame_ids, int* n_out) {
-    if (!h || nq < 0 || !n_out || (nq > 0 && !query)) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    if (!h || !n_out) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     *n_out = 0;
-    if (nq > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
-    int rc = set_device(h); if (rc) return rc;
-    const int n_elig = eligible_prefix(h, query_frame_id, h->params.min_gap);
-    if (n_elig == 0) return LCM_OK;
-    if (!out_scores) return fail(LCM_ERR_INVALID_ARG, "out_scores is NULL");
-    rc = upload_rows(h, h->d_qbuf, h->d_qbuf_bytes, query, nq, std::max(nq, 1), false); if (rc) return rc;
-    rc = ensure_dev(h->d_qcounts, h->d_qcounts_n, 1); if (rc) return rc;
-    int32_t nqc = nq;
-    HIP_TRY(hipMemcpyAsync(h->d_qcounts, &nqc, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    rc = score_prefix(h, (const uint32_t*)h->d_qbuf, h->d_qcounts, 0, 0, nq, n_elig, out_scores); if (rc) return rc;
-    if (out_frame_ids) for (int s = 0; s < n_elig; ++s) out_frame_ids[s] = h->frames[s].id;
-    *n_out = n_elig;
-    return LCM_OK;
+    int t = -1;
+    int rc = lcm_query_submit(h, query, nq, query_frame_id, &t); if (rc) return rc;
+    return lcm_query_collect(h, t, out_scores, out_frame_ids, lcm_db_size(h), n_out);
 }
 
 int lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
@@ -779,40 +837,38 @@ int lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, 
     if (!h || !n_out || cap < 0) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     *n_out = 0;
     int rc = set_device(h); if (rc) return rc;
-    const int n_elig = eligible_prefix(h, current_frame_id, h->params.min_gap);
     int q_kp = n_keypoints;
-    h->h_scores.resize((size_t)std::max(n_elig, 1));
+    int t = -1;
     if (query) {
         if (nq < 0) return fail(LCM_ERR_INVALID_ARG, "negative row count");
         if (q_kp < 0) q_kp = nq;
-        if (n_elig > 0) {
-            int n = 0;
-            rc = lcm_query_scores(h, query, nq, current_frame_id, h->h_scores.data(), nullptr, &n); if (rc) return rc;
-        }
+        rc = lcm_query_submit(h, query, nq, current_frame_id, &t); if (rc) return rc;
     } else {
-        // the current frame is already stored: use its device rows as the query
-        int slot = -1;
-        {
-            int lo = 0, hi = (int)h->frames.size();
-            while (lo < hi) { int mid = (lo + hi) / 2; if (h->frames[mid].id < current_frame_id) lo = mid + 1; else hi = mid; }
-            if (lo < (int)h->frames.size() && h->frames[lo].id == current_frame_id) slot = lo;
-        }
+        // the current frame is already stored: its device rows are the query, nothing is uploaded
+        const int slot = find_slot(h, current_frame_id);
         if (slot < 0) return fail(LCM_ERR_NOT_FOUND, "frame id %d is not stored", current_frame_id);
         nq = h->frames[slot].n;
         q_kp = h->frames[slot].n_kp;
         if (nq > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
-        rc = score_prefix(h, (const uint32_t*)h->d_rows, h->d_counts, (uint32_t)h->stride_rows * LCM_DESC_WORDS, (uint32_t)slot, nq,
-                          n_elig, h->h_scores.data());
+        rc = acquire_query_slot(h, &t); if (rc) return rc;
+        QuerySlot& q = h->qslots[t];
+        q.query_id = current_frame_id;
+        rc = enqueue_query(h, q, (const uint32_t*)(h->d_rows + (size_t)slot * h->stride_rows * LCM_DESC_BYTES), nq,
+                           eligible_prefix(h, current_frame_id, h->params.min_gap));
         if (rc) return rc;
+        q.busy = true;
     }
+    QuerySlot& q = h->qslots[t];
+    HIP_TRY(hipEventSynchronize(q.done));
+    q.busy = false;
     int k = 0, total = 0;
-    for (int s = 0; s < n_elig; ++s) {
+    for (int s = 0; s < q.n_elig; ++s) {
         double sim;
-        if (lcm_loop_test(&h->params, &h->h_scores[s], q_kp, h->frames[s].n_kp, &sim)) {
+        if (lcm_loop_test(&h->params, &q.h_scores[s], q_kp, h->frames[s].n_kp, &sim)) {
             if (k < cap && out) {
                 out[k].current_frame_id = current_frame_id;
                 out[k].matched_frame_id = h->frames[s].id;
-                out[k].num_matches = (int32_t)h->h_scores[s].good_count;
+                out[k].num_matches = (int32_t)q.h_scores[s].good_count;
                 out[k].similarity_score = sim;
                 ++k;
             }

@@ -25,12 +25,17 @@ struct ScoreArgs {
     const uint32_t* db_rows;     // stored frames, same layout
     const int32_t*  db_counts;
     uint32_t        db_stride_words;
-    const WorkItem* items;
+    const WorkItem* items;       // NULL => implicit items (online queries: nothing to upload), see imp_* below
     void*           scores;      // lcm_score records (8 bytes each)
     uint32_t*       keys;        // optional: best packed key per query row, keys[pair * keys_stride + row]
     uint32_t        keys_stride;
     int32_t         ratio;
     int32_t         dist_floor;
+    // Implicit items (items == NULL): ONE query frame of imp_nq rows at q_rows, cut into imp_chunks chunks of
+    // imp_chunk_rows rows (1 chunk = whole frame), against stored slots [0, imp_total) in runs of imp_spi slots.
+    // Workgroup b: chunk c = b % imp_chunks, run g = b / imp_chunks, out_offset = g * imp_spi * imp_chunks + c.
+    uint32_t        imp_chunks, imp_chunk_rows, imp_spi, imp_total;
+    int32_t         imp_nq;
 };
 
 // Launch the pair-scoring kernel over n_items work items.  max_query_rows = largest row count of any query

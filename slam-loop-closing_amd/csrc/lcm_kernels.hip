@@ -118,8 +118,19 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
     if (tid == 0) { red_min[0] = red_min[1] = 0xFFFFFFFFu; red_sum[0] = red_sum[1] = 0u; }
     __syncthreads();
 
-    const WorkItem it = a.items[blockIdx.x];
-    const int nq = a.q_counts[it.q_frame];
+    WorkItem it;
+    int nq;
+    if (a.items) {
+        it = a.items[blockIdx.x];
+        nq = a.q_counts[it.q_frame];
+    } else {                                   // implicit item, derived from blockIdx (see ScoreArgs)
+        const uint32_t c = blockIdx.x % a.imp_chunks, g = blockIdx.x / a.imp_chunks;
+        it.q_frame = c;
+        it.slot_begin = g * a.imp_spi;
+        it.n_slots = min(a.imp_spi, a.imp_total - it.slot_begin);
+        it.out_offset = it.slot_begin * a.imp_chunks + c;
+        nq = min((int)a.imp_chunk_rows, a.imp_nq - (int)(c * a.imp_chunk_rows));
+    }
 
     // ---- load this lane's query rows: row = j*THREADS + tid (consecutive lanes -> consecutive 32-byte rows)
     uint32_t q[QPT][8];
@@ -286,8 +297,19 @@ __global__ __launch_bounds__(256) void k_score_trainlane(ScoreArgs a) {
     __shared__ uint32_t red_min, red_sum;
 
     const int tid = threadIdx.x;
-    const WorkItem it = a.items[blockIdx.x];
-    const int nq = a.q_counts[it.q_frame];
+    WorkItem it;
+    int nq;
+    if (a.items) {
+        it = a.items[blockIdx.x];
+        nq = a.q_counts[it.q_frame];
+    } else {
+        const uint32_t c = blockIdx.x % a.imp_chunks, g = blockIdx.x / a.imp_chunks;
+        it.q_frame = c;
+        it.slot_begin = g * a.imp_spi;
+        it.n_slots = min(a.imp_spi, a.imp_total - it.slot_begin);
+        it.out_offset = it.slot_begin * a.imp_chunks + c;
+        nq = min((int)a.imp_chunk_rows, a.imp_nq - (int)(c * a.imp_chunk_rows));
+    }
     const uint4* qbase = reinterpret_cast<const uint4*>(a.q_rows + (size_t)it.q_frame * a.q_stride_words);
 
     for (uint32_t s = 0; s < it.n_slots; ++s) {

@@ -295,7 +295,8 @@ def test_fused_on_device_loop_test(matcher, oracle, pkg):
 
 def test_short_database_split_mode_all_regimes(matcher, oracle, pkg):
     """lcm_query_scores cuts a pair's query rows over 8 / 4 / 2 / 1 workgroups depending on how many stored frames are
-    eligible (< 160 / < 320 / < 640 / more).  Every regime must give the single-workgroup answer."""
+    eligible (< 256: 8 pieces, < 3072: 4, < 6144: 2, more: 1).  Every regime must give the single-workgroup answer
+    (LCM_SPLIT=0 forces the unsplit path; the full-size sharded test covers it through lcm_all_vs_all)."""
     fs = pkg.synth.make_frames(700, 600, seed=57, ragged=True, dup_frac=0.2)
     fs.counts[50] = 0
     gap = 1
@@ -303,7 +304,7 @@ def test_short_database_split_mode_all_regimes(matcher, oracle, pkg):
     try:
         fill(matcher, fs)
         p = oracle.default_params(min_gap=gap)
-        for cur in (100, 159, 161, 250, 500, 699):
+        for cur in (100, 255, 257, 500, 699):
             scores, ids = matcher.query_scores(fs.frame(cur), int(fs.ids[cur]))
             assert len(scores) == cur                                   # ids == positions, gap 1
             want, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, [cur] * cur, list(range(cur)), p, n_threads=8)
@@ -316,6 +317,36 @@ def test_short_database_split_mode_all_regimes(matcher, oracle, pkg):
         scores, _ = matcher.query_scores(big.frame(0), 120)
         want = [oracle.pair_score(big.frame(0), fs.frame(i), p) for i in (0, 50, 119)]
         assert [scores[0], scores[50], scores[119]] == want
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
+
+
+def test_async_submit_collect_pipeline(matcher, oracle, pkg):
+    """Streaming with up to 4 queries in flight: results equal the synchronous path and the batch oracle."""
+    fs = pkg.synth.make_frames(60, 700, seed=77, ragged=True, dup_frac=0.3)
+    gap = 2
+    matcher.set_params(min_gap=gap)
+    try:
+        matcher.clear()
+        got = [None] * fs.n_frames
+        pending = []
+        for f in range(fs.n_frames):
+            pending.append((matcher.query_submit(fs.frame(f), int(fs.ids[f])), f))
+            matcher.append(int(fs.ids[f]), fs.frame(f))
+            if len(pending) == 4:                               # the ring is full: a 5th submit must be refused
+                with pytest.raises(pkg.LcmError) as e:
+                    matcher.query_submit(fs.frame(f), int(fs.ids[f]))
+                assert e.value.code == -4
+                t, g = pending.pop(0)
+                got[g], ids = matcher.query_collect(t)
+                assert ids.tolist() == [int(fs.ids[i]) for i in range(fs.n_frames) if fs.ids[g] - fs.ids[i] >= gap]
+        for t, g in pending:
+            got[g], _ = matcher.query_collect(t)
+        want, _ = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap))
+        np.testing.assert_array_equal(np.concatenate(got), want)
+        with pytest.raises(pkg.LcmError):
+            matcher.query_collect(0)                            # nothing in flight on that ticket
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
