@@ -44,7 +44,8 @@ struct LoopCandidate {               // include/loop_closing.hpp:22-27, identica
     double similarity_score;
 };
 
-class LoopClosingSystem {
+// exported from liblcm_hip.so (built with -fvisibility=hidden): C++ callers link against the class directly
+class __attribute__((visibility("default"))) LoopClosingSystem {
 public:
     // include/loop_closing.hpp:31 — same defaults.  device_id / shard_* are additions with defaults that keep the
     // reference's two-argument construction valid.
