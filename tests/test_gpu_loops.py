@@ -3,7 +3,13 @@ streaming append, sharded == single."""
 import numpy as np
 import pytest
 
+from conftest import fast_all_vs_all, fast_detect_loops
+
 pytestmark = pytest.mark.gpu
+
+
+def cand_tuples(c):
+    return [(int(r["current_frame_id"]), int(r["matched_frame_id"]), int(r["num_matches"]), float(r["similarity_score"])) for r in c]
 
 
 def fill(m, fs, positions=None):
@@ -41,8 +47,8 @@ def test_all_vs_all_bit_exact(matcher, oracle, pkg, n_frames, max_desc, gap, rag
     try:
         fill(matcher, fs)
         got, offs = gpu_all_vs_all(matcher)
-        want, woffs = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap))
-        np.testing.assert_array_equal(offs, woffs)
+        want, woffs = fast_all_vs_all(oracle, fs, oracle.default_params(min_gap=gap))
+        np.testing.assert_array_equal(offs.astype(np.int64), woffs)
         np.testing.assert_array_equal(got, want)
         assert len(got) == pkg.synth.n_pairs_all_vs_all(n_frames, gap)
         info = matcher.launch_info()
@@ -84,14 +90,16 @@ def test_detect_loops_finds_revisits(matcher, oracle, pkg):
     try:
         fill(matcher, fs)
         total = 0
+        p = oracle.default_params(min_gap=10)
         for cur in range(10, 48):
-            want = oracle.detect_loops(fs.rows, fs.counts, fs.ids, cur, oracle.default_params(min_gap=10))
             got = matcher.detect_loops(int(fs.ids[cur]))
-            np.testing.assert_array_equal(got["matched_frame_id"], want["matched_frame_id"])
-            np.testing.assert_array_equal(got["num_matches"], want["num_matches"])
-            np.testing.assert_array_equal(got["similarity_score"], want["similarity_score"])
+            assert cand_tuples(got) == fast_detect_loops(oracle, fs, cur, p)
             total += len(got)
         assert total > 0
+        # and the scalar oracle's own detectLoops on two frames
+        for cur in (20, 47):
+            want = oracle.detect_loops(fs.rows, fs.counts, fs.ids, cur, p)
+            assert cand_tuples(matcher.detect_loops(int(fs.ids[cur]))) == cand_tuples(want)
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
@@ -110,7 +118,7 @@ def test_streaming_append_equals_batch(matcher, oracle, pkg):
             online.append(s.copy())
             matcher.append(int(fs.ids[f]), fs.frame(f))
         online = np.concatenate(online)
-        want, _ = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap))
+        want, _ = fast_all_vs_all(oracle, fs, oracle.default_params(min_gap=gap))
         np.testing.assert_array_equal(online, want)
         # and the stored rows read back unchanged
         for slot in (0, 17, 49):
@@ -137,7 +145,7 @@ def test_sharded_equals_single(matcher, oracle, pkg):
             fill(matcher, fs, pkg.sharding.owned_positions(fs.n_frames, r, world))
             s, _ = gpu_all_vs_all(matcher, q_ids=fs.ids, d_rows=d_rows, d_counts=d_counts, stride=fs.stride_rows)
             shards.append(s)
-            want_r, _ = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap), r, world)
+            want_r, _ = fast_all_vs_all(oracle, fs, oracle.default_params(min_gap=gap), r, world)
             np.testing.assert_array_equal(s, want_r)
         merged, moffs = pkg.sharding.merge_shard_scores(shards, fs.ids, gap)
         np.testing.assert_array_equal(merged, single)
@@ -222,7 +230,7 @@ def test_every_kernel_variant_is_bit_exact(matcher, oracle, pkg, variant):
     try:
         fill(matcher, fs)
         got, offs = gpu_all_vs_all(matcher)
-        want, woffs = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap))
+        want, woffs = fast_all_vs_all(oracle, fs, oracle.default_params(min_gap=gap))
         np.testing.assert_array_equal(got, want)
         # pair mode (keys) through the same variant
         for a, b in [(20, 2), (11, 9), (9, 11), (25, 4)]:
@@ -274,14 +282,14 @@ def test_fused_on_device_loop_test(matcher, oracle, pkg):
         got, n_pairs = matcher.all_vs_all_loops()
         assert n_pairs == pkg.synth.n_pairs_all_vs_all(fs.n_frames, gap)
         p = oracle.default_params(min_gap=gap)
+        scores, offs = fast_all_vs_all(oracle, fs, p)
         want = []
         for c in range(fs.n_frames):
-            for i in range(fs.n_frames):
-                if fs.ids[c] - fs.ids[i] >= gap:
-                    s = oracle.pair_score(fs.frame(c), fs.frame(i), p)
-                    ok, sim = oracle.loop_test(int(s["good_count"]), int(fs.counts[c]) + c % 3, int(fs.counts[i]) + i % 3, p)
-                    if ok:
-                        want.append((int(fs.ids[c]), int(fs.ids[i]), int(s["good_count"]), sim))
+            for k, i in enumerate(i for i in range(fs.n_frames) if fs.ids[c] - fs.ids[i] >= gap):
+                sc = scores[int(offs[c]) + k]
+                ok, sim = oracle.loop_test(int(sc["good_count"]), int(fs.counts[c]) + c % 3, int(fs.counts[i]) + i % 3, p)
+                if ok:
+                    want.append((int(fs.ids[c]), int(fs.ids[i]), int(sc["good_count"]), sim))
         assert len(want) > 0
         assert [(int(r["current_frame_id"]), int(r["matched_frame_id"]), int(r["num_matches"]), float(r["similarity_score"]))
                 for r in got] == want
@@ -343,7 +351,7 @@ def test_async_submit_collect_pipeline(matcher, oracle, pkg):
                 assert ids.tolist() == [int(fs.ids[i]) for i in range(fs.n_frames) if fs.ids[g] - fs.ids[i] >= gap]
         for t, g in pending:
             got[g], _ = matcher.query_collect(t)
-        want, _ = oracle.all_vs_all(fs.rows, fs.counts, fs.ids, oracle.default_params(min_gap=gap))
+        want, _ = fast_all_vs_all(oracle, fs, oracle.default_params(min_gap=gap))
         np.testing.assert_array_equal(np.concatenate(got), want)
         with pytest.raises(pkg.LcmError):
             matcher.query_collect(0)                            # nothing in flight on that ticket
