@@ -325,8 +325,9 @@ int lcm_create(const lcm_params* params, int device_id, void* stream, lcm_handle
     if (device_id < 0 || device_id >= ndev) return fail(LCM_ERR_INVALID_ARG, "device_id %d out of range [0,%d)", device_id, ndev);
     lcm_handle* h = new (std::nothrow) lcm_handle();
     if (!h) return fail(LCM_ERR_OOM, "host allocation failed");
-    if (params) h->params = *params; else lcm_params_default(&h->params);
+    lcm_params_default(&h->params);
     h->device = device_id;
+    if (params && lcm_set_params(h, params) != LCM_OK) { delete h; return LCM_ERR_INVALID_ARG; }
     auto bail = [&](int rc) { lcm_destroy(h); return rc; };
     if (hipSetDevice(device_id) != hipSuccess) return bail(fail(LCM_ERR_HIP, "hipSetDevice(%d) failed", device_id));
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
@@ -376,7 +377,9 @@ void lcm_destroy(lcm_handle* h) {
 
 int lcm_set_params(lcm_handle* h, const lcm_params* p) {
     if (!h || !p) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
-    if (p->ratio < 0 || p->dist_floor < 0 || p->min_gap < 0) return fail(LCM_ERR_INVALID_ARG, "negative parameter");
+    if (p->ratio < 0 || p->dist_floor < 0 || p->min_gap < 0 || p->min_matches < 0) return fail(LCM_ERR_INVALID_ARG, "negative parameter");
+    if (p->ratio > 65536 || p->dist_floor > 65536) return fail(LCM_ERR_INVALID_ARG, "ratio / dist_floor above 65536 (distances are <= 256)");
+    if (!(p->sim_threshold == p->sim_threshold)) return fail(LCM_ERR_INVALID_ARG, "sim_threshold is NaN");
     h->params = *p;
     h->plan.key = 0;
     return LCM_OK;

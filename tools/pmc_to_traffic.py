@@ -7,7 +7,7 @@ import json
 import sys
 
 
-def kernel_sum(path, counter, kernel_substr="k_score_rowlane"):
+def kernel_sum(path, counter, kernel_substr="k_score_rowlane<256, 8, false, false>"):   # the loop-search kernel only
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
         if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
