@@ -193,6 +193,7 @@ def main():
     n_desc = args.desc or n_desc
     if args.frames:
         n_frames = args.frames
+        wl_desc += f" [frame count overridden: {n_frames}]"
     elif args.workload == "auto" and world > 1:
         per_rank = pkg.synth.n_pairs_all_vs_all(base_frames, args.gap)
         n_frames = pkg.synth.frames_for_pairs(per_rank * world, args.gap)     # weak scaling
