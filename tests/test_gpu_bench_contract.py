@@ -1,0 +1,61 @@
+"""bench.py's output contract, on small workloads: one JSON line with the required keys at N = 1, and the N > 1 code
+path (process group, cyclic sharding, all-gather of score records, merge check) rehearsed with 2 gloo ranks sharing
+the one GPU of the box (RCCL itself needs one GPU per rank; the driver runs that at round end)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def last_json(stdout):
+    lines = [l for l in stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_contract():
+    r = subprocess.run([sys.executable, "bench.py", "--frames", "120", "--desc", "500", "--steps", "2", "--warmup", "1",
+                        "--cpu-seconds", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "distances/s" and d["data"] == "synthetic" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] == "hbm"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["cores"] >= 1
+    assert cb["gpu_vs_cpu_sample_mismatches"] == 0
+    assert d["config"]["pairs_per_step"] == (120 - 30) * (120 - 29) // 2
+    assert d["value"] > 0 and d["roofline_valu"]["bound"] == "valu"
+
+
+def test_two_rank_rehearsal_gloo():
+    port = free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--frames", "150",
+                        "--desc", "500", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--cpu-seconds", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["sharding"] == "cyclic by frame"
+    assert d["config"]["pairs_per_step"] == (150 - 30) * (150 - 29) // 2       # both shards together = the whole search
+    assert d["value"] > 0

@@ -358,3 +358,31 @@ def test_async_submit_collect_pipeline(matcher, oracle, pkg):
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+def test_create_use_destroy_cycles(pkg):
+    """Handles come and go (every scratch buffer, pinned ring, stream and event is released) and two can coexist."""
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, (700, 32), dtype=np.uint8) for _ in range(12)]
+    ref = None
+    for cycle in range(25):
+        p = pkg.default_params()
+        p.min_gap = 1
+        a = pkg.Matcher(p)
+        b = pkg.Matcher(p) if cycle % 5 == 0 else None
+        for i, f in enumerate(frames):
+            a.append(i, f)
+            if b is not None:
+                b.append(i, f)
+        s, _ = a.query_scores(frames[3], 50)
+        if b is not None:
+            s2, _ = b.query_scores(frames[3], 50)
+            np.testing.assert_array_equal(s, s2)
+            b.close()
+        idx, d = a.match_pair(frames[0], frames[1])
+        t = a.query_submit(frames[5], 60)                     # destroyed with a query still in flight
+        if ref is None:
+            ref = (s.copy(), idx.copy(), d.copy())
+        np.testing.assert_array_equal(s, ref[0])
+        np.testing.assert_array_equal(idx, ref[1])
+        a.close()
