@@ -95,3 +95,66 @@ def all_gather_scores(local: "torch.Tensor", n_local: int, group=None) -> List[n
         else dist.all_gather(list(recv.view(world, cap).unbind(0)), send, group=group)
     host = recv.view(world, cap).cpu().numpy()
     return [host[r, : lens[r]].view(SCORE_DTYPE).copy() for r in range(world)]
+
+
+class ShardedLoopSearch:
+    """One process per GPU: this rank's slice of a frame-sharded loop search.
+
+    `scorer` is a Matcher-like object (the HIP library in production; tests inject a CPU stand-in) exposing
+    append(frame_id, rows), query_scores(rows, frame_id) -> (scores, ids), __len__.  `group` is a torch.distributed
+    process group (None = default group; pass world == 1 to run without torch.distributed).
+
+    Online use mirrors LoopClosingSystem::processFrame (include/loop_closing.hpp:34): every rank calls
+    process_frame(rows, frame_id) for EVERY frame, in the same order; the frame is scored against the frames this
+    rank owns, the per-shard records are all-gathered, and every rank gets the same merged, ascending-id answer."""
+
+    def __init__(self, scorer, rank: int = 0, world: int = 1, group=None, device=None, params=None):
+        self.scorer, self.rank, self.world, self.group, self.device = scorer, int(rank), int(world), group, device
+        self.params = params            # object with min_matches / sim_threshold (loop test); None -> scorer.params
+        self.ids: List[int] = []        # ids of ALL frames seen, arrival order == ascending
+        self.kp: List[int] = []         # keypoint counts of all frames (similarity denominator)
+
+    # -- helpers -----------------------------------------------------------------------------------------
+    def _gather(self, local: np.ndarray) -> List[np.ndarray]:
+        if self.world == 1:
+            return [local]
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(local).view(np.int64).copy())
+        if self.device is not None:
+            t = t.to(self.device)
+        return all_gather_scores(t, len(local), self.group)
+
+    def _loop_params(self):
+        p = self.params if self.params is not None else self.scorer.params
+        return int(p.min_matches), float(p.sim_threshold), int(p.min_gap)
+
+    # -- online -------------------------------------------------------------------------------------------
+    def process_frame(self, rows: np.ndarray, frame_id: int, n_keypoints: int = -1):
+        """Returns (scores, stored_ids, candidates): merged records of this frame against every eligible stored
+        frame of ALL shards, in ascending stored-frame order, and the loop candidates among them."""
+        if self.ids and frame_id <= self.ids[-1]:
+            raise ValueError("frame ids must increase")
+        local, _ = self.scorer.query_scores(rows, frame_id)
+        shards = self._gather(np.asarray(local))
+        min_matches, thr, gap = self._loop_params()
+        ids = np.asarray(self.ids, np.int64)
+        e = int(np.searchsorted(ids, frame_id - max(gap, 1), side="right")) if len(ids) else 0
+        merged = np.zeros(e, SCORE_DTYPE)
+        for r, s in enumerate(shards):
+            want = max(0, (e - r + self.world - 1) // self.world)
+            if len(s) != want:
+                raise ValueError(f"rank {r}: expected {want} records, got {len(s)}")
+            merged[r::self.world][:want] = s
+        nq = int(len(rows)) if n_keypoints < 0 else int(n_keypoints)
+        cands = []
+        for i in range(e):
+            den = min(nq, self.kp[i])
+            good = int(merged[i]["good_count"])
+            if den > 0 and good >= min_matches and (good / den) > thr:       # README.md:123-126, IEEE double
+                cands.append((int(frame_id), int(self.ids[i]), good, good / den))
+        pos = len(self.ids)
+        if pos % self.world == self.rank:
+            self.scorer.append(frame_id, rows) if n_keypoints < 0 else self.scorer.append(frame_id, rows, n_keypoints)
+        self.ids.append(int(frame_id))
+        self.kp.append(nq)
+        return merged, np.asarray(self.ids[:e], np.int32), cands

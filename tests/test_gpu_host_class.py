@@ -90,3 +90,19 @@ def test_sharded_host_objects_partition_the_candidates(pkg, oracle):
     finally:
         for s in shards:
             s.close()
+
+
+def test_sharded_loop_search_driver_world1(pkg, oracle):
+    """sharding.ShardedLoopSearch with the real Matcher as its scorer (world 1: no process group needed)."""
+    fs = pkg.synth.make_frames(30, 300, seed=5, dup_frac=0.3)
+    p = pkg.default_params()
+    p.min_gap = 4
+    with pkg.Matcher(p) as m:
+        search = pkg.sharding.ShardedLoopSearch(m)
+        got = []
+        for f in range(fs.n_frames):
+            merged, ids, cands = search.process_frame(fs.frame(f), int(fs.ids[f]))
+            got += cands
+        op = oracle.default_params(min_gap=4)
+        want = [t for c in range(fs.n_frames) for t in fast_detect_loops(oracle, fs, c, op)]
+        assert got == want and len(want) > 0

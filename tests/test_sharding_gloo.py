@@ -71,3 +71,59 @@ def test_ownership_and_offsets(pkg):
             assert sh.owned_positions(len(ids), r, world).tolist() == list(range(r, len(ids), world))
         assert tot.tolist() == e.tolist()
     assert sh.eligible_counts(ids, 0).tolist() == list(range(len(ids)))      # gap 0 still never pairs a frame with itself
+
+
+class _OracleScorer:
+    """CPU stand-in for Matcher in the host-logic tests: same interface, distances from the oracle."""
+
+    def __init__(self, oracle, params):
+        self.oracle, self.params, self.frames = oracle, params, []
+
+    def __len__(self):
+        return len(self.frames)
+
+    def append(self, frame_id, rows, n_keypoints=-1):
+        self.frames.append((int(frame_id), np.ascontiguousarray(rows)))
+
+    def query_scores(self, rows, frame_id):
+        gap = max(int(self.params.min_gap), 1)
+        el = [(i, r) for i, r in self.frames if frame_id - i >= gap]
+        out = np.zeros(len(el), dtype=[("good_count", "<u4"), ("min_dist", "<u2"), ("n_train", "<u2")])
+        for k, (_, r) in enumerate(el):
+            out[k] = self.oracle.pair_score(rows, r, self.params)
+        return out, np.array([i for i, _ in el], np.int32)
+
+
+def _online_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from conftest import load_oracle, load_package
+
+    pkg, orc = load_package(), load_oracle()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fs = pkg.synth.make_frames(18, 40, seed=7, ragged=True, dup_frac=0.5)
+        p = orc.default_params(min_gap=2, min_matches=3, sim_threshold=0.05)
+        search = pkg.sharding.ShardedLoopSearch(_OracleScorer(orc, p), rank, world)
+        all_scores, all_cands = [], []
+        for f in range(fs.n_frames):
+            merged, ids, cands = search.process_frame(fs.frame(f), int(fs.ids[f]))
+            assert ids.tolist() == [int(i) for i in fs.ids if fs.ids[f] - i >= 2]
+            all_scores.append(merged)
+            all_cands += cands
+        full, _ = orc.all_vs_all(fs.rows, fs.counts, fs.ids, p)
+        assert np.array_equal(np.concatenate(all_scores), full)
+        want = [tuple(map(lambda x: x.item() if hasattr(x, "item") else x, (c["current_frame_id"], c["matched_frame_id"], c["num_matches"], c["similarity_score"])))
+                for cur in range(fs.n_frames) for c in orc.detect_loops(fs.rows, fs.counts, fs.ids, cur, p)]
+        assert all_cands == want and len(want) > 0
+        assert len(search.scorer) == len(range(rank, fs.n_frames, world))          # only owned frames were stored
+        np.save(os.path.join(out_dir, f"online{rank}.npy"), np.array([len(want)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_online_sharded_search(tmp_path):
+    port = _free_port()
+    mp.spawn(_online_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert int(np.load(tmp_path / "online0.npy")[0]) == int(np.load(tmp_path / "online1.npy")[0]) > 0
