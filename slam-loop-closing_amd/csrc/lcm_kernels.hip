@@ -7,14 +7,15 @@
 //
 // This is integer VALU work: 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 (accumulating) per distance, no MFMA.
 //
-// Variant 0 — "row-per-lane, train rows through the scalar unit":
+// k_score_rowlane — "row-per-lane, train rows through the scalar unit" (variants 0 / 1, the default):
 //   * every lane OWNS up to QPT query rows in VGPRs (8 dwords each), loaded once per work item with coalesced
 //     16-byte loads (row-major 32-byte rows: lane l reads row l — the 32-byte descriptor database layout);
 //   * the train rows are wave-uniform: they are read with s_load_dwordx16 from the constant address space into
 //     SGPRs and used directly as the scalar operand of v_xor_b32 — no LDS traffic, no VGPRs, no cross-lane work
 //     in the inner loop;
-//   * per-query running minimum is a packed key (dist << 22 | train_idx) folded with v_min3_u32, so the lowest
-//     train index wins ties for free (strict-'<' scan order of OpenCV's batchDistance);
+//   * per-query running minimum folded with v_min3_u32: the bare distance for the loop search (ARGMIN = false: a
+//     LoopCandidate carries no train index), or a packed key (dist << 22 | train_idx) when match lists are wanted
+//     (ARGMIN = true) — the lowest train index then wins ties for free (strict-'<' scan of OpenCV's batchDistance);
 //   * per pair, the min-of-mins and the good-match count are LDS-atomic reductions (ds_min_u32 / ds_add_u32) over
 //     the workgroup's lanes.
 //
@@ -31,10 +32,6 @@ namespace lcm {
 
 typedef const uint32_t __attribute__((address_space(4))) * sptr_t;   // constant AS => SMEM (s_load) when uniform
 typedef const int32_t __attribute__((address_space(4))) * siptr_t;
-
-__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
-    return min(min(a, b), c);   // v_min3_u32
-}
 
 // One query row (8 VGPRs) against TWO train rows (16 SGPRs, rows t and t+1): both distances, both packed keys and the
 // fold into the running minimum, as ONE asm statement so that the instruction order is exactly the one below.
