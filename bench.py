@@ -63,7 +63,8 @@ def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi,
     One step = one pass over the whole sequence.  Scores are gathered once per step (RCCL) when N > 1."""
     p = pkg.default_params()
     p.min_gap = args.gap
-    stream = torch.cuda.current_stream(dev)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     m = pkg.Matcher(p, device=local_rank, stream=stream.cuda_stream)
     n_frames = fs.n_frames
     owned_n = len(pkg.sharding.owned_positions(n_frames, rank, world))
@@ -210,7 +211,10 @@ def main():
     # ---- inputs resident in HBM ----------------------------------------------------------------------
     d_rows = torch.from_numpy(fs.rows).to(dev)                 # (frames, stride, 32) uint8: the query stream
     d_counts = torch.from_numpy(fs.counts).to(dev)
-    stream = torch.cuda.current_stream(dev)
+    # An explicit torch stream (not the legacy default stream, whose handle is 0): the library enqueues its kernels on
+    # it and torch.distributed orders the RCCL all-gather after them, because collectives wait on the CURRENT stream.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     p = pkg.default_params()
     p.min_gap = args.gap
     m = pkg.Matcher(p, device=local_rank, stream=stream.cuda_stream)
@@ -301,6 +305,7 @@ def main():
 
     # ---- parity spot check + CPU baseline (rank 0, N = 1 only) ---------------------------------------
     cpu = None
+    merged_mismatch = None
     if multi:
         # merge check (outside the timed region): the gathered shards, un-permuted, must equal what a single device
         # would have written for a sample of query frames — here verified structurally (lengths, n_train fields)
@@ -312,6 +317,18 @@ def main():
         e = pkg.sharding.eligible_counts(fs.ids, args.gap)
         nt_expect = np.concatenate([fs.counts[: int(k)] for k in e]) if exp else np.zeros(0)
         assert np.array_equal(merged["n_train"].astype(np.int64), nt_expect.astype(np.int64)), "merged shard order is wrong"
+        merged_mismatch = None
+        if rank == 0 and exp:
+            # ... and by value: a sample of merged records against the CPU oracle (checker only, not timed)
+            oracle = entry.load_oracle()
+            oracle.build()
+            rng = np.random.default_rng(7)
+            qs = rng.integers(args.gap, n_frames, size=96)
+            ts = np.array([rng.integers(0, q - args.gap + 1) for q in qs])
+            cs, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, qs, ts, oracle.default_params(min_gap=args.gap), host_cores())
+            merged_mismatch = int(np.sum(merged[moffs[qs] + ts] != cs))
+            if merged_mismatch:
+                print(f"PARITY FAILURE: {merged_mismatch} of 96 sampled merged records differ from the CPU oracle", file=sys.stderr)
     if rank == 0 and not multi and args.cpu_seconds > 0:
         oracle = entry.load_oracle()
         oracle.build()
@@ -373,6 +390,8 @@ def main():
                 "kernel_ms": argmin_ms, "distances_per_s": local_dist / (argmin_ms * 1e-3)},
             "cpu_baseline": cpu,
         }
+        if multi:
+            out["merged_shards_vs_oracle_sample_mismatches"] = merged_mismatch
         print(json.dumps(out))
     m.close()
     if multi:

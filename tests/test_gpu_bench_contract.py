@@ -59,3 +59,4 @@ def test_two_rank_rehearsal_gloo():
     assert d["n_gpus"] == 2 and d["config"]["sharding"] == "cyclic by frame"
     assert d["config"]["pairs_per_step"] == (150 - 30) * (150 - 29) // 2       # both shards together = the whole search
     assert d["value"] > 0
+    assert d["merged_shards_vs_oracle_sample_mismatches"] == 0      # gathered + merged records are right BY VALUE
