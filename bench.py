@@ -43,6 +43,18 @@ WORKLOADS = {
 }
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def host_cores():
     """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -122,7 +134,7 @@ def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi,
     merged, _ = pkg.sharding.merge_shard_scores(shards, fs.ids, args.gap)
     assert len(merged) == pkg.synth.n_pairs_all_vs_all(n_frames, args.gap)
     if rank == 0:
-        print(json.dumps({
+        emit(({
             "metric": METRIC, "value": total_dist * args.steps / elapsed, "unit": "distances/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if args.workload == "auto" else "strong", "vs_baseline": None,
@@ -155,6 +167,13 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="exercise the N > 1 code path (process group, all-gather) even at world size 1")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU rehearsal of the N > 1 path)")
     args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  Native libraries chat on fd 1 (RCCL prints a 5-line version banner when
+    # a communicator is created), so fd 1 is pointed at stderr for the whole run and the JSON line goes to the saved fd.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     import torch  # first: the process then has ONE HIP runtime (torch's), which liblcm_hip.so binds to
     import torch.distributed as dist
@@ -392,7 +411,7 @@ def main():
         }
         if multi:
             out["merged_shards_vs_oracle_sample_mismatches"] = merged_mismatch
-        print(json.dumps(out))
+        emit(out)
     m.close()
     if multi:
         dist.destroy_process_group()
