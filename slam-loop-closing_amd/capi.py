@@ -144,7 +144,12 @@ def _ptr(a: Optional[np.ndarray]):
 
 
 class Matcher:
-    """One matcher handle bound to one HIP device (one process per GPU)."""
+    """One matcher handle bound to one HIP device (one process per GPU).
+
+    `stream` is a hipStream_t handle as an int (e.g. `torch.cuda.Stream(...).cuda_stream`); None or 0 (the legacy default
+    stream's handle) makes the library create its own non-blocking stream.  When results are consumed by another
+    framework on the device (torch.distributed collectives on the buffers lcm_all_vs_all filled), pass that framework's
+    CURRENT stream — an explicit one — so its work is ordered after the kernels; see bench.py."""
 
     def __init__(self, params: Optional[Params] = None, device: int = 0, stream: Optional[int] = None):
         self._lib = load_library()
