@@ -89,7 +89,6 @@ def test_cfg2_full_database_sampled_vs_oracle_and_sharded(matcher, oracle, pkg):
     against the oracle's tuned CPU path (itself checked against the scalar oracle in test_oracle_numpy.py) and 3
     against the scalar oracle; the 4-way cyclic-sharded run must merge to the byte-identical array (K10); both kernel
     variants (distance-only / full keys) must agree."""
-    import torch  # noqa: F401  (only to fail early if the image is broken)
     fs = pkg.synth.make_frames(1000, 2000, seed=pkg.synth.BASE_SEED + 2)
     gap = 30
     matcher.set_params(min_gap=gap)
