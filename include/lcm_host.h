@@ -29,6 +29,8 @@ LCM_API int  lcs_process_frame(lcs_system* s, const uint8_t* desc, int rows, int
 LCM_API int  lcs_match_features(lcs_system* s, int frame1_id, int frame2_id, lcm_dmatch* out, int cap, int* n_out);
 /* detectLoops(current_frame_id) (include/loop_closing.hpp:48). */
 LCM_API int  lcs_detect_loops(lcs_system* s, int current_frame_id, lcm_loop_candidate* out, int cap, int* n_out);
+/* matches between the previous and the current frame computed by the last lcs_process_frame (README.md:96-97) */
+LCM_API int  lcs_get_consecutive_matches(const lcs_system* s, lcm_dmatch* out, int cap, int* n_out);
 LCM_API int  lcs_num_frames(const lcs_system* s);                       /* getFrames().size()        hpp:60 */
 LCM_API int  lcs_num_loop_closures(const lcs_system* s);                /* getLoopClosures().size()  hpp:63 */
 LCM_API int  lcs_get_loop_closures(const lcs_system* s, lcm_loop_candidate* out, int cap, int* n_out);

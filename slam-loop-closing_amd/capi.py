@@ -375,6 +375,7 @@ _HOST_SIGNATURES = {
     "lcs_process_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     "lcs_match_features": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
     "lcs_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i32p]),
+    "lcs_get_consecutive_matches": (C.c_int, [_vp, _vp, C.c_int, _i32p]),
     "lcs_num_frames": (C.c_int, [_vp]),
     "lcs_num_loop_closures": (C.c_int, [_vp]),
     "lcs_get_loop_closures": (C.c_int, [_vp, _vp, C.c_int, _i32p]),
@@ -432,6 +433,12 @@ class LoopClosingSystem:
         out = np.zeros(cap, CANDIDATE_DTYPE)
         n = C.c_int32(0)
         self._hcheck(self._lib.lcs_get_loop_closures(self._s, out.ctypes.data_as(_vp), cap, C.byref(n)))
+        return out[: n.value]
+
+    def getConsecutiveMatches(self, cap: int = 65536) -> np.ndarray:
+        out = np.zeros(cap, DMATCH_DTYPE)
+        n = C.c_int32(0)
+        self._hcheck(self._lib.lcs_get_consecutive_matches(self._s, out.ctypes.data_as(_vp), cap, C.byref(n)))
         return out[: n.value]
 
     def numFrames(self) -> int:

@@ -43,8 +43,12 @@ void LoopClosingSystem::processFrame(const uint8_t* descriptors, int rows, int n
     f.id = frame_id;
     f.num_keypoints = num_keypoints < 0 ? rows : num_keypoints;
     f.descriptors.assign(descriptors, descriptors + (size_t)rows * 32);
-    // loop-closure check against the frames stored so far (the current frame is the query, README.md:100,122) ...
     frames_.push_back(std::move(f));
+    // consecutive-frame matching (README.md:96-97): previous frame = query, current = train, as the tree's own
+    // incremental loop orders them (src/main.cpp:1154 matchFeatures(lastKF, cur)); pose / triangulation are out of scope
+    consecutive_matches_.clear();
+    if (frames_.size() >= 2) consecutive_matches_ = matchFeatures(frames_[frames_.size() - 2], frames_.back());
+    // loop-closure check against the frames stored so far (the current frame is the query, README.md:100,122) ...
     std::vector<LoopCandidate> found = detectLoops(frame_id);
     loop_closures_.insert(loop_closures_.end(), found.begin(), found.end());
     // ... then the frame joins the device database if this rank owns its position
@@ -166,6 +170,15 @@ int lcs_detect_loops(lcs_system* s, int current_frame_id, lcm_loop_candidate* ou
         if (!c.empty()) memcpy(out, c.data(), c.size() * sizeof(lcm_loop_candidate));
         *n_out = (int)c.size();
     });
+}
+
+int lcs_get_consecutive_matches(const lcs_system* s, lcm_dmatch* out, int cap, int* n_out) {
+    if (!s || !n_out) return LCM_ERR_INVALID_ARG;
+    const auto& v = s->sys.getConsecutiveMatches();
+    if ((int)v.size() > cap) return LCM_ERR_CAPACITY;
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(lcm_dmatch));
+    *n_out = (int)v.size();
+    return LCM_OK;
 }
 
 int lcs_num_frames(const lcs_system* s) { return s ? (int)s->sys.getFrames().size() : 0; }

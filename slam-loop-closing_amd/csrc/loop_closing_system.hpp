@@ -66,6 +66,10 @@ public:
     // BASELINE.json's north_star spells this one detectLoopClosure.
     std::vector<LoopCandidate> detectLoopClosure(int current_frame_id) { return detectLoops(current_frame_id); }
 
+    // Matches between the previous and the current frame, as processFrame's consecutive-frame step computes them
+    // (README.md:96-97 "Feature matching between consecutive frames"; what estimatePose / triangulatePoints would consume).
+    const std::vector<DMatch>& getConsecutiveMatches() const { return consecutive_matches_; }
+
     const std::vector<Frame>& getFrames() const { return frames_; }                      // hpp:60
     const std::vector<LoopCandidate>& getLoopClosures() const { return loop_closures_; }  // hpp:63
 
@@ -80,6 +84,7 @@ public:
 private:
     std::vector<Frame> frames_;
     std::vector<LoopCandidate> loop_closures_;
+    std::vector<DMatch> consecutive_matches_;
     lcm_handle* matcher_ = nullptr;      // stands where cv::Ptr<cv::BFMatcher> matcher_ stood (hpp:73)
     double loop_threshold_;              // hpp:75
     int min_loop_gap_;                   // hpp:76

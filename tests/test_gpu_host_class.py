@@ -19,10 +19,15 @@ def test_process_frames_online_equals_oracle(pkg, oracle, tmp_path):
     gap, thr = 6, 0.15
     sys_ = pkg.LoopClosingSystem(thr, gap)
     try:
+        p = oracle.default_params(min_gap=gap, sim_threshold=thr)
         for f in range(fs.n_frames):
             sys_.processFrame(fs.frame(f), int(fs.ids[f]))
+            if f in (1, 17, fs.n_frames - 1):                 # consecutive-frame matches: previous = query, current = train
+                cm = sys_.getConsecutiveMatches()
+                om, _ = oracle.match_features(fs.frame(f - 1), fs.frame(f), p)
+                for k in ("query_idx", "train_idx", "img_idx", "distance"):
+                    np.testing.assert_array_equal(cm[k], om[k])
         assert sys_.numFrames() == fs.n_frames
-        p = oracle.default_params(min_gap=gap, sim_threshold=thr)
         fast = [t for c in range(fs.n_frames) for t in fast_detect_loops(oracle, fs, c, p)]
         got = sys_.getLoopClosures()
         assert len(fast) > 0 and cand_tuples(got) == fast
