@@ -197,7 +197,9 @@ LCM_API int  lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const
                                   lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out);
 LCM_API int  lcm_last_launch_info(const lcm_handle* h, lcm_launch_info* info);
 
-/* Select the pair-match kernel variant: 0 = default, see DESIGN.md (for A/B measurement only). */
+/* Select the kernel variant of the bulk / online scoring (A/B measurement; results are identical):
+ * 0 = query-row-per-lane, distances only (default); 1 = same, tracking (dist, idx) keys; 2 / 3 = the
+ * train-row-per-lane mapping with LDS-staged queries and wavefront shuffle reductions, distances only / keys. */
 LCM_API int  lcm_set_kernel_variant(lcm_handle* h, int variant);
 
 /* Device scratch helpers so a host program needs no other allocator (plain hipMalloc/hipFree/hipMemcpy). */
