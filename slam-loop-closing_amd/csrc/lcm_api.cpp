@@ -971,7 +971,21 @@ int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_que
     a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
     a.items = P.d_items; a.scores = d_scores; a.keys = nullptr; a.keys_stride = 0;
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
-    rc = launch_and_time(h, a, (uint32_t)P.items.size(), P.max_q_rows, false); if (rc) return rc;
+    // Very large searches go out as several launches (<= 2^20 work items, a few seconds each): no single kernel runs
+    // long enough to meet a compute-queue timeout, and the stream stays responsive.
+    constexpr size_t MAX_ITEMS_PER_LAUNCH = 1u << 20;
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    uint32_t launches = 0, biggest = 0;
+    for (size_t first = 0; first < P.items.size(); first += MAX_ITEMS_PER_LAUNCH) {
+        const uint32_t n = (uint32_t)std::min(MAX_ITEMS_PER_LAUNCH, P.items.size() - first);
+        a.items = P.d_items + first;
+        hipError_t e = lcm::launch_score(a, n, P.max_q_rows, false, h->variant, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        ++launches; biggest = std::max(biggest, n);
+    }
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    h->info_pending = true;
+    h->info.launches = launches; h->info.workgroups = biggest;
     h->info.pairs = P.n_pairs; h->info.distances = P.distances; h->info.algo_bytes = P.algo_bytes;
     return LCM_OK;
 }

@@ -141,3 +141,39 @@ def test_cfg2_full_database_sampled_vs_oracle_and_sharded(matcher, oracle, pkg):
         matcher.dev_free(d_rows); matcher.dev_free(d_counts)
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+def test_search_larger_than_one_launch(pkg, oracle, monkeypatch):
+    """More than 2^20 work items: the bulk search goes out as several launches; the records must not notice."""
+    fs = pkg.synth.make_frames(1500, 256, seed=11)
+    p = pkg.default_params()
+    p.min_gap = 30
+
+    def run(chunk):
+        if chunk:
+            monkeypatch.setenv("LCM_CHUNK", str(chunk))
+        else:
+            monkeypatch.delenv("LCM_CHUNK", raising=False)
+        with pkg.Matcher(p) as m:
+            for f in range(fs.n_frames):
+                m.append(int(fs.ids[f]), fs.frame(f))
+            n, offs = m.all_vs_all_plan()
+            d = m.dev_alloc(n * 8)
+            m.all_vs_all(d, n)
+            out = np.zeros(n, pkg.capi.SCORE_DTYPE)
+            m.sync()
+            m.dev_download(d, out)
+            m.dev_free(d)
+            return out, offs, m.launch_info().launches
+
+    one, offs, l1 = run(0)
+    many, offs2, l2 = run(1)                                   # 1,081,185 single-pair items -> 2 launches
+    assert len(one) == pkg.synth.n_pairs_all_vs_all(1500, 30) == 1081185
+    assert l1 == 1 and l2 == 2
+    np.testing.assert_array_equal(one, many)
+    np.testing.assert_array_equal(offs, offs2)
+    rng = np.random.default_rng(3)
+    qs = rng.integers(30, 1500, 300)
+    ts = np.array([rng.integers(0, q - 29) for q in qs])
+    cpu, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, qs, ts, oracle.default_params(min_gap=30), n_threads=8)
+    np.testing.assert_array_equal(one[offs[qs].astype(np.int64) + ts], cpu)
