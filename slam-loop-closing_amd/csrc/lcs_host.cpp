@@ -44,18 +44,26 @@ void LoopClosingSystem::processFrame(const uint8_t* descriptors, int rows, int n
     f.num_keypoints = num_keypoints < 0 ? rows : num_keypoints;
     f.descriptors.assign(descriptors, descriptors + (size_t)rows * 32);
     frames_.push_back(std::move(f));
-    // consecutive-frame matching (README.md:96-97): previous frame = query, current = train, as the tree's own
-    // incremental loop orders them (src/main.cpp:1154 matchFeatures(lastKF, cur)); pose / triangulation are out of scope
-    consecutive_matches_.clear();
-    if (frames_.size() >= 2) consecutive_matches_ = matchFeatures(frames_[frames_.size() - 2], frames_.back());
-    // loop-closure check against the frames stored so far (the current frame is the query, README.md:100,122) ...
-    std::vector<LoopCandidate> found = detectLoops(frame_id);
-    loop_closures_.insert(loop_closures_.end(), found.begin(), found.end());
-    // ... then the frame joins the device database if this rank owns its position
-    const size_t pos = frames_.size() - 1;
-    if (ownsPosition(pos)) {
-        const Frame& s = frames_.back();
-        if (lcm_db_append(matcher_, s.id, s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_db_append");
+    const size_t n_loops_before = loop_closures_.size();
+    try {
+        // consecutive-frame matching (README.md:96-97): previous frame = query, current = train, as the tree's own
+        // incremental loop orders them (src/main.cpp:1154 matchFeatures(lastKF, cur)); pose / triangulation are out of scope
+        consecutive_matches_.clear();
+        if (frames_.size() >= 2) consecutive_matches_ = matchFeatures(frames_[frames_.size() - 2], frames_.back());
+        // loop-closure check against the frames stored so far (the current frame is the query, README.md:100,122) ...
+        std::vector<LoopCandidate> found = detectLoops(frame_id);
+        loop_closures_.insert(loop_closures_.end(), found.begin(), found.end());
+        // ... then the frame joins the device database if this rank owns its position
+        const size_t pos = frames_.size() - 1;
+        if (ownsPosition(pos)) {
+            const Frame& s = frames_.back();
+            if (lcm_db_append(matcher_, s.id, s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_db_append");
+        }
+    } catch (...) {
+        // strong guarantee: a frame that could not be processed leaves no trace (host list, loop list, device DB agree)
+        frames_.pop_back();
+        loop_closures_.resize(n_loops_before);
+        throw;
     }
 }
 
