@@ -37,7 +37,8 @@ def m_score_dtype(m):
     return load_package().capi.SCORE_DTYPE
 
 
-@pytest.mark.parametrize("n_frames,max_desc,gap,ragged", [(100, 500, 30, False), (40, 300, 5, True), (12, 2000, 3, True)])
+@pytest.mark.parametrize("n_frames,max_desc,gap,ragged", [(100, 500, 30, False), (40, 300, 5, True), (12, 2000, 3, True),
+                                                          (14, 1000, 2, True), (14, 1400, 2, True)])   # 128- and 192-thread workgroups
 def test_all_vs_all_bit_exact(matcher, oracle, pkg, n_frames, max_desc, gap, ragged):
     """cfg1 (100 x 500, gap 30) is BASELINE.json's configs[0]; the others stress ragged / full-size frames."""
     fs = pkg.synth.make_frames(n_frames, max_desc, seed=pkg.synth.BASE_SEED + 1, ragged=ragged, dup_frac=0.2)

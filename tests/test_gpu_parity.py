@@ -12,7 +12,7 @@ def rnd(rng, n):
 # (n_query, n_train): SURVEY.md §8c K5 ragged shapes + wave/workgroup/chunk edges (64 lanes, 256 threads,
 # 2048-row query chunks, 4-row train padding)
 SHAPES = [(1, 1), (1, 2), (2, 1), (3, 5), (64, 65), (63, 64), (65, 63), (1, 2000), (2000, 1), (500, 500),
-          (513, 7), (1024, 1025), (1537, 33), (1999, 1777), (2000, 2000), (2048, 2048), (2049, 11), (4100, 130),
+          (513, 7), (1024, 1025), (1025, 9), (1500, 40), (1536, 5), (1537, 33), (1999, 1777), (2000, 2000), (2048, 2048), (2049, 11), (4100, 130),
           (7, 4097)]
 
 
