@@ -117,6 +117,9 @@ def test_cfg2_full_database_sampled_vs_oracle_and_sharded(matcher, oracle, pkg):
         assert len(full) == 470935 == pkg.synth.n_pairs_all_vs_all(1000, gap)
         info = matcher.launch_info()
         assert info.distances == 470935 * 2000 * 2000
+        # canary, deliberately loose (measured 655 ms = 2.87e12 distances/s): a silent fallback or a de-optimised
+        # build would be several times slower
+        assert info.kernel_ms < 1300, f"cfg2 pass took {info.kernel_ms:.0f} ms"
         assert (full["n_train"] == 2000).all() and (full["good_count"] <= 2000).all() and (full["good_count"] >= 1).all()
 
         matcher.set_kernel_variant(1)

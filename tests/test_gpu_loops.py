@@ -210,10 +210,20 @@ def test_snapshot_restore_round_trip(matcher, pkg, tmp_path):
         after, offs2 = gpu_all_vs_all(matcher)
         np.testing.assert_array_equal(before, after)
         np.testing.assert_array_equal(offs, offs2)
-        with open(path, "r+b") as f:
-            f.write(b"garbage!")
+        blob = open(path, "rb").read()
+        with open(path, "wb") as f:                             # truncated file: loud, and the handle stays usable
+            f.write(blob[: len(blob) // 2])
         with pytest.raises(pkg.LcmError):
             matcher.load(path)
+        with open(path, "wb") as f:
+            f.write(b"garbage!" + blob[8:])
+        with pytest.raises(pkg.LcmError):
+            matcher.load(path)
+        with open(path, "wb") as f:
+            f.write(blob)
+        matcher.load(path)
+        again, _ = gpu_all_vs_all(matcher)
+        np.testing.assert_array_equal(again, before)
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
