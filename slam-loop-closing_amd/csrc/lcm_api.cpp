@@ -536,6 +536,12 @@ int lcm_db_load(lcm_handle* h, const char* path) {
     }
     fclose(f);
     if (!rc) rc = lcm_sync(h);
+    if (rc && metas.size() == hd.n_frames && hd.version == 1) {
+        // the file turned out to be bad after the old contents were dropped: leave an EMPTY database, not half of one
+        const std::string why = g_err;
+        (void)lcm_db_clear(h);
+        g_err = why;
+    }
     return rc;
 }
 
