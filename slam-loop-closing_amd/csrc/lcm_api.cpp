@@ -525,7 +525,8 @@ int lcm_db_load(lcm_handle* h, const char* path) {
         metas.resize(hd.n_frames);
         if (hd.n_frames && fread(metas.data(), sizeof(FrameMeta), hd.n_frames, f) != hd.n_frames) rc = fail(LCM_ERR_INVALID_ARG, "%s is truncated", path);
     }
-    if (!rc) rc = lcm_db_clear(h);
+    bool cleared = false;
+    if (!rc) { rc = lcm_db_clear(h); cleared = (rc == LCM_OK); }
     if (!rc) rc = lcm_db_reserve(h, (int)hd.n_frames, (int)std::max<uint32_t>(hd.max_rows, 1));
     std::vector<uint8_t> buf;
     for (size_t s = 0; !rc && s < metas.size(); ++s) {
@@ -536,7 +537,7 @@ int lcm_db_load(lcm_handle* h, const char* path) {
     }
     fclose(f);
     if (!rc) rc = lcm_sync(h);
-    if (rc && metas.size() == hd.n_frames && hd.version == 1) {
+    if (rc && cleared) {
         // the file turned out to be bad after the old contents were dropped: leave an EMPTY database, not half of one
         const std::string why = g_err;
         (void)lcm_db_clear(h);
