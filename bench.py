@@ -32,6 +32,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # issue costs on gfx950 (tools/valu_peak.hip, profiles/r01_valu_peak.txt): v_xor_b32 2 cycles and v_bcnt_u32_b32
 # 4 cycles per wave64 instruction per SIMD => 48 SIMD-cycles per 64 distances; 256 CUs x 4 SIMDs at 2.4 GHz.
 VALU_PEAK_DIST_PER_S = 256 * 4 * 64 / 48.0 * 2.4e9
+VALU_NOMINAL_DIST_PER_S = 256 * 4 * 64 / 32.0 * 2.4e9      # if every one of the 16 instructions issued in 2 cycles
 
 WORKLOADS = {
     # name: (frames, descriptors per frame, description)
@@ -150,6 +151,40 @@ def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi,
         dist.destroy_process_group()
 
 
+def cfg4_fused_extra(pkg, torch, dev, local_rank, gap):
+    """One step of BASELINE.json configs[3] at full size on this GPU: 5000 x 2000, lcm_all_vs_all_loops (score kernel,
+    scores stay in HBM, k_loop_test, candidate compaction).  Reported as an `extra` block of the N = 1 line."""
+    n_frames, n_desc, desc = WORKLOADS["cfg4"]
+    seed = pkg.synth.BASE_SEED + 4
+    fs = pkg.synth.make_frames(n_frames, n_desc, seed=seed)
+    d_rows = torch.from_numpy(fs.rows).to(dev)
+    stream = torch.cuda.current_stream(dev)
+    p = pkg.default_params()
+    p.min_gap = gap
+    m = pkg.Matcher(p, device=local_rank, stream=stream.cuda_stream)
+    m.reserve(n_frames, n_desc)
+    fb = fs.stride_rows * 32
+    for f in range(n_frames):
+        m.append_device(int(fs.ids[f]), d_rows.data_ptr() + f * fb, int(fs.counts[f]))
+    m.sync()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    cands, pairs = m.all_vs_all_loops(cap=1 << 21)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    info = m.launch_info()
+    out = {"workload": desc, "frames": n_frames, "descriptors_per_frame": n_desc, "min_gap": gap, "seed": seed,
+           "api": "lcm_all_vs_all_loops", "steps": 1, "ms_per_step": (t1 - t0) * 1e3, "pairs": int(pairs),
+           "distances": int(info.distances), "value": int(info.distances) / (t1 - t0), "unit": "distances/s",
+           "score_kernel_ms": info.kernel_ms, "k_loop_test_ms": info.aux_kernel_ms, "loop_candidates": int(len(cands)),
+           "k_loop_test_roofline": {"bound": "hbm", "bytes": int(pairs) * 8 + int(len(cands)) * 24,
+                                    "achieved_GBps": (int(pairs) * 8 + int(len(cands)) * 24) / max(info.aux_kernel_ms, 1e-6) / 1e6,
+                                    "peak_GBps": HBM_PEAK_GBPS}}
+    m.close()
+    del d_rows
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +199,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores this process may use")
     ap.add_argument("--mode", default="batch", help="batch (default: one all-vs-all pass per step) | stream (online: "
                     "per frame, score it against the database, then append it — BASELINE.json configs[4] shape)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra blocks of the default N = 1 line (cfg4 fused step)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the N > 1 code path (process group, all-gather) even at world size 1")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU rehearsal of the N > 1 path)")
     args = ap.parse_args()
@@ -208,13 +244,16 @@ def main():
     # ---- workload ------------------------------------------------------------------------------------
     wl = args.workload
     if wl == "auto":
-        wl = "cfg2"
+        # N = 8 is the configuration BASELINE.json's configs[2] / north_star name: 10000 x 2000 sharded over 8 GPUs.
+        # Other N: cfg2 (configs[1], "1 MI355X"), weak-scaled so that every rank keeps cfg2's pair count.
+        wl = "cfg3" if (world == 8 and not args.frames and args.mode == "batch") else "cfg2"
     base_frames, n_desc, wl_desc = WORKLOADS[wl]
     n_desc = args.desc or n_desc
+    fused = (wl == "cfg4")                      # configs[3]: filter + loop test on the device, only candidates leave HBM
     if args.frames:
         n_frames = args.frames
         wl_desc += f" [frame count overridden: {n_frames}]"
-    elif args.workload == "auto" and world > 1:
+    elif args.workload == "auto" and world > 1 and wl == "cfg2":
         per_rank = pkg.synth.n_pairs_all_vs_all(base_frames, args.gap)
         n_frames = pkg.synth.frames_for_pairs(per_rank * world, args.gap)     # weak scaling
         wl_desc = (f"cfg2 weak-scaled to {world} GPUs: {n_frames} frames x {n_desc} descriptors "
@@ -263,8 +302,13 @@ def main():
     else:
         lens = [n_local]
 
+    fused_out = {}
+
     def step():
-        if not multi:
+        if fused:
+            # lcm_all_vs_all_loops: score kernel -> scores stay in HBM -> k_loop_test -> compacted candidates -> host
+            fused_out["cands"], fused_out["pairs"] = m.all_vs_all_loops(cap=1 << 21, **q_args)
+        elif not multi:
             m.all_vs_all(scores.data_ptr(), n_local, **q_args)
         else:
             m.all_vs_all(send.data_ptr(), cap, **q_args)          # kernel writes straight into the send buffer
@@ -297,7 +341,8 @@ def main():
     info = m.launch_info()                                        # HIP events around the LAST step's kernel
     kernel_ms.append(info.kernel_ms)
     # a few more individually timed launches for a stable per-launch duration (outside the timed region)
-    for _ in range(min(3, max(args.steps - 1, 0))):
+    loop_test_ms = info.aux_kernel_ms if fused else None
+    for _ in range(min(3, max(args.steps - 1, 0)) if not fused else 0):
         m.all_vs_all((send if multi else scores).data_ptr(), cap if multi else n_local, **q_args)
         kernel_ms.append(m.launch_info().kernel_ms)
     kern_ms = float(np.mean(kernel_ms))
@@ -305,7 +350,7 @@ def main():
     local_dist = int(info.distances)
     # the same workload through the (dist, idx)-key kernel the pair mode uses: reported beside the headline number
     argmin_ms = None
-    if args.variant == 0:
+    if args.variant == 0 and not fused:
         m.set_kernel_variant(1)
         ms = []
         for _ in range(2):
@@ -348,6 +393,8 @@ def main():
             merged_mismatch = int(np.sum(merged[moffs[qs] + ts] != cs))
             if merged_mismatch:
                 print(f"PARITY FAILURE: {merged_mismatch} of 96 sampled merged records differ from the CPU oracle", file=sys.stderr)
+    if fused:
+        fused_scores = m.last_bulk_scores()                  # what the fused call left in HBM (parity sample below)
     if rank == 0 and not multi and args.cpu_seconds > 0:
         oracle = entry.load_oracle()
         oracle.build()
@@ -355,7 +402,7 @@ def main():
         rng = np.random.default_rng(123)
         got = np.zeros(n_local, pkg.capi.SCORE_DTYPE)
         torch.cuda.synchronize(dev)
-        got[:] = scores.cpu().numpy().view(pkg.capi.SCORE_DTYPE)[:n_local]
+        got[:] = fused_scores if fused else scores.cpu().numpy().view(pkg.capi.SCORE_DTYPE)[:n_local]
         qs = rng.integers(args.gap, n_frames, size=262144)
         ts = np.array([rng.integers(0, q - args.gap + 1) for q in qs])
         op = oracle.default_params(min_gap=args.gap)
@@ -397,10 +444,16 @@ def main():
                        "sharding": "cyclic by frame" if world > 1 else "none", "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else
+                         "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command "
+                         "(gfx950 corrections applied), NOT measured in this run",
                          "kernel": "k_score_rowlane", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "note": "this path is VALU-bound by ~200x (0.016 algorithmic bytes per distance); see roofline_valu"},
             "roofline_valu": {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
                               "frac": kern_rate / VALU_PEAK_DIST_PER_S,
+                              "nominal_peak": VALU_NOMINAL_DIST_PER_S, "nominal_frac": kern_rate / VALU_NOMINAL_DIST_PER_S,
+                              "nominal_model": "all 16 instructions at the guide's 2-cycle wave64 issue on a SIMD-32 "
+                                               "(v_bcnt_u32_b32 measures 4.19: tools/valu_class.hip)",
                               "model": "8 v_xor_b32 (2 cyc) + 8 v_bcnt_u32_b32 (4 cyc) per 64 distances per SIMD, "
                                        "1024 SIMDs @ 2.4 GHz"},
             "argmin_kernel": None if argmin_ms is None else {
@@ -411,6 +464,16 @@ def main():
         }
         if multi:
             out["merged_shards_vs_oracle_sample_mismatches"] = merged_mismatch
+        if fused:
+            out["fused"] = {"api": "lcm_all_vs_all_loops", "k_loop_test_ms": loop_test_ms,
+                            "loop_candidates": int(len(fused_out["cands"])),
+                            "note": "roofline.kernel_ms is the score kernel inside the fused call; ms_per_step covers "
+                                    "score kernel + k_loop_test + candidate download + host sort"}
+        if not multi and args.workload == "auto" and not args.frames and not args.desc and not args.no_extras:
+            m.close()
+            del scores, d_rows
+            torch.cuda.empty_cache()
+            out["extra"] = {"cfg4_fused": cfg4_fused_extra(pkg, torch, dev, local_rank, args.gap)}
         emit(out)
     m.close()
     if multi:

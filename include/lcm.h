@@ -105,6 +105,8 @@ typedef struct lcm_launch_info {
     uint64_t algo_bytes;        /* sum n_train*32 per pair + n_query*32 per query frame + 8 per pair */
     uint32_t launches;          /* kernel launches that made up the call */
     uint32_t workgroups;        /* workgroups of the (largest) launch */
+    double   aux_kernel_ms;     /* device time of the call's follow-up kernel, 0 if none: k_loop_test of
+                                 * lcm_all_vs_all_loops */
 } lcm_launch_info;
 
 typedef struct lcm_handle lcm_handle;
@@ -196,11 +198,20 @@ LCM_API int  lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const
                                   const int32_t* q_ids, const int32_t* q_keypoints, int n_q_frames, int q_stride_rows,
                                   lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out);
 LCM_API int  lcm_last_launch_info(const lcm_handle* h, lcm_launch_info* info);
+/* Device address and record count of the score array the last lcm_all_vs_all_loops left in HBM (same order as
+ * lcm_all_vs_all would write; valid until the next bulk call on this handle; NULL / 0 if there is none). */
+LCM_API int  lcm_last_bulk_scores(const lcm_handle* h, const void** d_scores, size_t* n_records);
 
 /* Select the kernel variant of the bulk / online scoring (A/B measurement; results are identical):
  * 0 = query-row-per-lane, distances only (default); 1 = same, tracking (dist, idx) keys; 2 / 3 = the
  * train-row-per-lane mapping with LDS-staged queries and wavefront shuffle reductions, distances only / keys. */
 LCM_API int  lcm_set_kernel_variant(lcm_handle* h, int variant);
+
+/* Measurement knobs (defaults are the measured optima; results never depend on them):
+ *   LCM_TUNE_ITEM_SLOTS   stored frames per work item of the bulk search, 1..64; 0 = automatic
+ *   LCM_TUNE_ONLINE_SPLIT query rows per lane of the online split mode: 1, 2, 4; 0 = never split; -1 = automatic */
+typedef enum lcm_tuning { LCM_TUNE_ITEM_SLOTS = 0, LCM_TUNE_ONLINE_SPLIT = 1 } lcm_tuning;
+LCM_API int  lcm_set_tuning(lcm_handle* h, int knob, int value);
 
 /* Device scratch helpers so a host program needs no other allocator (plain hipMalloc/hipFree/hipMemcpy). */
 LCM_API int  lcm_dev_alloc(lcm_handle* h, size_t bytes, void** d_ptr);

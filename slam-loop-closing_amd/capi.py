@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblcm_hip.so")
 DESC_BYTES = 32
 KEY_SHIFT = 22
+TUNE_ITEM_SLOTS, TUNE_ONLINE_SPLIT = 0, 1      # lcm_tuning
 
 
 class LcmError(RuntimeError):
@@ -44,7 +45,8 @@ class LoopCandidate(C.Structure):
 
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("pairs", C.c_uint64), ("distances", C.c_uint64),
-                ("algo_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32)]
+                ("algo_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32),
+                ("aux_kernel_ms", C.c_double)]
 
 
 SCORE_DTYPE = np.dtype([("good_count", "<u4"), ("min_dist", "<u2"), ("n_train", "<u2")])
@@ -94,7 +96,9 @@ _SIGNATURES = {
     "lcm_all_vs_all_loops": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lcm_last_launch_info": (C.c_int, [_vp, C.POINTER(LaunchInfo)]),
+    "lcm_last_bulk_scores": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "lcm_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
+    "lcm_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "lcm_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "lcm_dev_free": (C.c_int, [_vp, _vp]),
     "lcm_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -191,6 +195,9 @@ class Matcher:
     def set_kernel_variant(self, v: int):
         _check(self._lib.lcm_set_kernel_variant(self._h, v))
 
+    def set_tuning(self, knob: int, value: int):
+        _check(self._lib.lcm_set_tuning(self._h, knob, value))
+
     def sync(self):
         _check(self._lib.lcm_sync(self._h))
 
@@ -274,8 +281,8 @@ class Matcher:
         _check(self._lib.lcm_query_submit(self._h, _ptr(q), q.shape[0], query_frame_id, C.byref(t)))
         return t.value
 
-    def query_collect(self, ticket: int) -> Tuple[np.ndarray, np.ndarray]:
-        cap = max(len(self), 1)
+    def query_collect(self, ticket: int, cap: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        cap = max(len(self), 1) if cap is None else cap
         scores = np.zeros(cap, SCORE_DTYPE)
         ids = np.zeros(cap, np.int32)
         n = C.c_int32(0)
@@ -342,6 +349,16 @@ class Matcher:
                                               _vp(d_query_counts) if d_query_counts else None, _ptr(ids), _ptr(kps), nq,
                                               q_stride_rows, out.ctypes.data_as(_vp), cap, C.byref(n), C.byref(npairs)))
         return out[: n.value], npairs.value
+
+    def last_bulk_scores(self) -> np.ndarray:
+        """Download the score records the last all_vs_all_loops call left on the device."""
+        p, n = _vp(), C.c_size_t(0)
+        _check(self._lib.lcm_last_bulk_scores(self._h, C.byref(p), C.byref(n)))
+        out = np.zeros(n.value, SCORE_DTYPE)
+        if n.value:
+            self.sync()
+            self.dev_download(p.value, out)
+        return out
 
     def launch_info(self) -> LaunchInfo:
         info = LaunchInfo()

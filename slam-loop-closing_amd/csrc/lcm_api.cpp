@@ -9,6 +9,7 @@
 #include "../../include/lcm.h"
 
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -33,6 +34,16 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     g_err = buf;
     return code;
+}
+
+// Nothing may throw across the C boundary (include/lcm.h): every entry point that touches a std container runs inside
+// this guard, which turns std::bad_alloc into LCM_ERR_OOM and anything else into LCM_ERR_HIP + message.
+template <typename F>
+int guarded(F&& f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(LCM_ERR_OOM, "host allocation failed (std::bad_alloc)"); }
+    catch (const std::exception& e) { return fail(LCM_ERR_HIP, "unexpected C++ exception: %s", e.what()); }
+    catch (...) { return fail(LCM_ERR_HIP, "unexpected C++ exception"); }
 }
 
 #define HIP_TRY(expr)                                                                              \
@@ -61,11 +72,11 @@ constexpr int QUERY_SLOTS = 4;    // online queries that may be in flight at onc
 struct QuerySlot {                // everything one in-flight online query owns
     bool busy = false;
     int n_elig = 0, nq = 0, query_id = 0;
+    uint64_t db_generation = 0;   // h->db_generation at submit: a clear / load in between invalidates the ticket
     uint8_t* h_query = nullptr;   size_t h_query_bytes = 0;    // pinned staging of the query rows
     lcm_score* h_scores = nullptr; size_t h_scores_n = 0;      // pinned landing zone of the score records
     uint8_t* d_query = nullptr;   size_t d_query_bytes = 0;
     lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
-    lcm_score* d_partial = nullptr; size_t d_partial_n = 0;    // split mode: per-chunk partial records (unused)
     uint32_t* d_dist = nullptr;   size_t d_dist_n = 0;         // split mode: best distance per (pair, row)
     hipEvent_t done = nullptr;
 };
@@ -95,7 +106,11 @@ struct lcm_handle {
     hipStream_t copy_stream = nullptr;
     hipEvent_t db_ready = nullptr;     // last append landed (recorded on copy_stream)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_aux_start = nullptr, ev_aux_stop = nullptr;   // the follow-up kernel of a call (k_loop_test, ...)
+    bool aux_pending = false;
     int variant = 0;
+    int tune_item_slots = 0;           // 0 = automatic (pick_chunk)
+    int tune_online_split = -1;        // -1 = automatic (enqueue_query)
 
     // database arena
     uint8_t* d_rows = nullptr;
@@ -123,10 +138,12 @@ struct lcm_handle {
     lcm::WorkItem* d_items = nullptr; size_t d_items_n = 0;
     std::vector<uint32_t> h_keys;
     lcm_score* d_bulk_scores = nullptr; size_t d_bulk_scores_n = 0;   // lcm_all_vs_all_loops: scores stay on the device
+    size_t bulk_scores_valid = 0;                                     // records of the last fused call still in there
     int32_t* d_meta = nullptr; size_t d_meta_n = 0;
     lcm_loop_candidate* d_cands = nullptr; size_t d_cands_n = 0;
 
     QuerySlot qslots[QUERY_SLOTS];
+    uint64_t db_generation = 1;        // bumped whenever stored frames are dropped (lcm_db_clear / lcm_db_load)
     Plan plan;
     lcm_launch_info info{};
     bool info_pending = false;
@@ -250,8 +267,8 @@ int eligible_prefix(const lcm_handle* h, int query_id, int gap) {
     return lo;
 }
 
-int pick_chunk(size_t total_pairs) {
-    if (const char* e = getenv("LCM_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 64) return c; }   // tuning knob
+int pick_chunk(const lcm_handle* h, size_t total_pairs) {
+    if (h->tune_item_slots >= 1) return h->tune_item_slots;          // lcm_set_tuning(LCM_TUNE_ITEM_SLOTS)
     // Small items keep the tail of the launch short (an item is the unit the dispatcher balances): measured on cfg2,
     // 2 frames per item 656.4 ms, 4: 657.8, 8: 660.4, 16: 667.6.  Very large runs use 4 to bound the item list.
     return total_pairs >= (1u << 21) ? 4 : (total_pairs >= 4096 ? 2 : 1);
@@ -337,7 +354,8 @@ int lcm_create(const lcm_params* params, int device_id, void* stream, lcm_handle
     }
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(LCM_ERR_HIP, "hipStreamCreate(copy) failed"));
     if (hipEventCreateWithFlags(&h->db_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess)
+        hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess ||
+        hipEventCreate(&h->ev_aux_start) != hipSuccess || hipEventCreate(&h->ev_aux_stop) != hipSuccess)
         return bail(fail(LCM_ERR_HIP, "hipEventCreate failed"));
     for (int i = 0; i < STAGE_BUFS; ++i) {
         if (hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming) != hipSuccess)
@@ -357,7 +375,7 @@ void lcm_destroy(lcm_handle* h) {
     (void)hipFree(h->d_keys); (void)hipFree(h->d_scores); (void)hipFree(h->d_items); (void)hipFree(h->plan.d_items);
     (void)hipFree(h->d_bulk_scores); (void)hipFree(h->d_meta); (void)hipFree(h->d_cands);
     for (QuerySlot& q : h->qslots) {
-        (void)hipFree(q.d_query); (void)hipFree(q.d_scores); (void)hipFree(q.d_partial); (void)hipFree(q.d_dist);
+        (void)hipFree(q.d_query); (void)hipFree(q.d_scores); (void)hipFree(q.d_dist);
         if (q.h_query) (void)hipHostFree(q.h_query);
         if (q.h_scores) (void)hipHostFree(q.h_scores);
         if (q.done) (void)hipEventDestroy(q.done);
@@ -370,6 +388,8 @@ void lcm_destroy(lcm_handle* h) {
     if (h->db_ready) (void)hipEventDestroy(h->db_ready);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->ev_aux_start) (void)hipEventDestroy(h->ev_aux_start);
+    if (h->ev_aux_stop) (void)hipEventDestroy(h->ev_aux_stop);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -406,15 +426,29 @@ int lcm_set_kernel_variant(lcm_handle* h, int variant) {
     return LCM_OK;
 }
 
+int lcm_set_tuning(lcm_handle* h, int knob, int value) {
+    if (!h) return fail(LCM_ERR_INVALID_ARG, "NULL handle");
+    switch (knob) {
+        case LCM_TUNE_ITEM_SLOTS:
+            if (value < 0 || value > 64) return fail(LCM_ERR_INVALID_ARG, "item slots must be 0 (automatic) .. 64");
+            h->tune_item_slots = value; h->plan.key = 0; return LCM_OK;
+        case LCM_TUNE_ONLINE_SPLIT:
+            if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4)
+                return fail(LCM_ERR_INVALID_ARG, "online split must be -1 (automatic), 0 (off), 1, 2 or 4 rows per lane");
+            h->tune_online_split = value; return LCM_OK;
+        default: return fail(LCM_ERR_INVALID_ARG, "unknown tuning knob %d", knob);
+    }
+}
+
 /* ---- database ---------------------------------------------------------------------------------------- */
 
-int lcm_db_reserve(lcm_handle* h, int n_frames, int max_desc) {
+static int db_reserve_impl(lcm_handle* h, int n_frames, int max_desc) {
     if (!h || n_frames < 0 || max_desc < 0) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     int rc = set_device(h); if (rc) return rc;
     return grow_arena(h, std::max(n_frames, 1), std::max(max_desc, 1));
 }
 
-int lcm_db_append(lcm_handle* h, int frame_id, const uint8_t* desc, int n, int n_keypoints) {
+static int db_append_impl(lcm_handle* h, int frame_id, const uint8_t* desc, int n, int n_keypoints) {
     if (!h || (n > 0 && !desc)) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
     int rc = set_device(h); if (rc) return rc;
     rc = check_append(h, frame_id, n); if (rc) return rc;
@@ -440,7 +474,7 @@ int lcm_db_append(lcm_handle* h, int frame_id, const uint8_t* desc, int n, int n
     return LCM_OK;
 }
 
-int lcm_db_append_device(lcm_handle* h, int frame_id, const void* d_desc, int n, int n_keypoints) {
+static int db_append_device_impl(lcm_handle* h, int frame_id, const void* d_desc, int n, int n_keypoints) {
     if (!h || (n > 0 && !d_desc)) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
     int rc = set_device(h); if (rc) return rc;
     rc = check_append(h, frame_id, n); if (rc) return rc;
@@ -466,6 +500,9 @@ int lcm_db_clear(lcm_handle* h) {
     int rc = lcm_sync(h); if (rc) return rc;
     h->frames.clear();
     h->plan.key = 0;
+    // Tickets of queries submitted against the dropped frames stay collectable, but only to learn that: their records
+    // refer to slots that no longer exist (lcm_query_collect returns LCM_ERR_NOT_FOUND and frees the ticket).
+    ++h->db_generation;
     return LCM_OK;
 }
 
@@ -491,7 +528,7 @@ namespace {
 struct SnapHeader { char magic[8]; uint32_t version, n_frames, max_rows, reserved; };
 }
 
-int lcm_db_save(lcm_handle* h, const char* path) {
+static int db_save_impl(lcm_handle* h, const char* path) {
     if (!h || !path) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
     int rc = lcm_sync(h); if (rc) return rc;
     FILE* f = fopen(path, "wb");
@@ -512,33 +549,44 @@ int lcm_db_save(lcm_handle* h, const char* path) {
     return ok ? LCM_OK : fail(LCM_ERR_HIP, "writing %s failed", path);
 }
 
-int lcm_db_load(lcm_handle* h, const char* path) {
+static int db_load_impl(lcm_handle* h, const char* path) {
     if (!h || !path) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
     FILE* f = fopen(path, "rb");
     if (!f) return fail(LCM_ERR_NOT_FOUND, "cannot open %s", path);
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+    // Everything the header claims is checked against the file's real size BEFORE anything is allocated or the
+    // current database is touched: a corrupt or hostile header can neither trigger a huge allocation nor cost the
+    // caller the frames it already has.
+    struct stat st{};
+    if (fstat(fileno(f), &st) != 0 || st.st_size < 0) return fail(LCM_ERR_INVALID_ARG, "cannot stat %s", path);
+    const uint64_t file_bytes = (uint64_t)st.st_size;
     SnapHeader hd{};
-    std::vector<FrameMeta> metas;
-    int rc = LCM_OK;
     if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "LCMDB01", 8) != 0 || hd.version != 1 || hd.max_rows > 65535u)
-        rc = fail(LCM_ERR_INVALID_ARG, "%s is not an lcm database snapshot", path);
-    if (!rc) {
-        metas.resize(hd.n_frames);
-        if (hd.n_frames && fread(metas.data(), sizeof(FrameMeta), hd.n_frames, f) != hd.n_frames) rc = fail(LCM_ERR_INVALID_ARG, "%s is truncated", path);
+        return fail(LCM_ERR_INVALID_ARG, "%s is not an lcm database snapshot", path);
+    if (hd.n_frames > 0x7FFFFFFFu || sizeof hd + (uint64_t)hd.n_frames * sizeof(FrameMeta) > file_bytes)
+        return fail(LCM_ERR_INVALID_ARG, "%s: header claims %u frames but the file holds %llu bytes", path, hd.n_frames,
+                    (unsigned long long)file_bytes);
+    std::vector<FrameMeta> metas(hd.n_frames);
+    if (hd.n_frames && fread(metas.data(), sizeof(FrameMeta), hd.n_frames, f) != hd.n_frames)
+        return fail(LCM_ERR_INVALID_ARG, "%s is truncated", path);
+    uint64_t need = sizeof hd + (uint64_t)hd.n_frames * sizeof(FrameMeta);
+    for (size_t s = 0; s < metas.size(); ++s) {
+        if (metas[s].n < 0 || (uint32_t)metas[s].n > hd.max_rows) return fail(LCM_ERR_INVALID_ARG, "%s: bad row count in frame %zu", path, s);
+        if (s > 0 && metas[s].id <= metas[s - 1].id) return fail(LCM_ERR_INVALID_ARG, "%s: frame ids are not increasing", path);
+        need += (uint64_t)metas[s].n * LCM_DESC_BYTES;
     }
-    bool cleared = false;
-    if (!rc) { rc = lcm_db_clear(h); cleared = (rc == LCM_OK); }
-    if (!rc) rc = lcm_db_reserve(h, (int)hd.n_frames, (int)std::max<uint32_t>(hd.max_rows, 1));
-    std::vector<uint8_t> buf;
+    if (need > file_bytes) return fail(LCM_ERR_INVALID_ARG, "%s is truncated (%llu bytes, needs %llu)", path,
+                                       (unsigned long long)file_bytes, (unsigned long long)need);
+    int rc = lcm_db_clear(h); if (rc) return rc;
+    rc = lcm_db_reserve(h, (int)hd.n_frames, (int)std::max<uint32_t>(hd.max_rows, 1));
+    std::vector<uint8_t> buf((size_t)hd.max_rows * LCM_DESC_BYTES + 1);
     for (size_t s = 0; !rc && s < metas.size(); ++s) {
-        if (metas[s].n < 0 || (uint32_t)metas[s].n > hd.max_rows) { rc = fail(LCM_ERR_INVALID_ARG, "%s: bad row count", path); break; }
-        buf.resize((size_t)metas[s].n * LCM_DESC_BYTES + 1);
-        if (metas[s].n && fread(buf.data(), LCM_DESC_BYTES, (size_t)metas[s].n, f) != (size_t)metas[s].n) { rc = fail(LCM_ERR_INVALID_ARG, "%s is truncated", path); break; }
+        if (metas[s].n && fread(buf.data(), LCM_DESC_BYTES, (size_t)metas[s].n, f) != (size_t)metas[s].n) { rc = fail(LCM_ERR_INVALID_ARG, "%s: read error", path); break; }
         rc = lcm_db_append(h, metas[s].id, buf.data(), metas[s].n, metas[s].n_kp);
     }
-    fclose(f);
     if (!rc) rc = lcm_sync(h);
-    if (rc && cleared) {
-        // the file turned out to be bad after the old contents were dropped: leave an EMPTY database, not half of one
+    if (rc) {
+        // an I/O or device error after the old contents were dropped: leave an EMPTY database, not half of one
         const std::string why = g_err;
         (void)lcm_db_clear(h);
         g_err = why;
@@ -651,7 +699,7 @@ static int filter_keys(const lcm_handle* h, const std::vector<uint32_t>& keys, i
     return LCM_OK;
 }
 
-int lcm_match_pair(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
+static int match_pair_impl(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
                    int32_t* train_idx, uint16_t* dist, int* n_matches) {
     if (!h || nq < 0 || nt < 0) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     if (n_matches) *n_matches = 0;
@@ -667,7 +715,7 @@ int lcm_match_pair(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* t
     return LCM_OK;
 }
 
-int lcm_match_features(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
+static int match_features_impl(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt,
                        lcm_dmatch* out, int* n_out, int* min_dist) {
     if (!h || nq < 0 || nt < 0 || !n_out) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     *n_out = 0;
@@ -679,7 +727,7 @@ int lcm_match_features(lcm_handle* h, const uint8_t* query, int nq, const uint8_
     return filter_keys(h, keys, nq, out, n_out, min_dist);
 }
 
-int lcm_match_stored(lcm_handle* h, int query_frame_id, int train_frame_id, lcm_dmatch* out, int cap, int* n_out, int* min_dist) {
+static int match_stored_impl(lcm_handle* h, int query_frame_id, int train_frame_id, lcm_dmatch* out, int cap, int* n_out, int* min_dist) {
     if (!h || !n_out) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     *n_out = 0;
     if (min_dist) *min_dist = -1;
@@ -721,7 +769,7 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
     q.n_elig = n_elig; q.nq = nq;
     if (n_elig <= 0) { HIP_TRY(hipEventRecord(q.done, h->stream)); return LCM_OK; }
     int rc = wait_db(h); if (rc) return rc;
-    static const int split_env = [] { const char* e = getenv("LCM_SPLIT"); return e ? atoi(e) : -1; }();   // tuning knob
+    const int split_env = h->tune_online_split;              // lcm_set_tuning(LCM_TUNE_ONLINE_SPLIT); -1 = automatic
     int qpt = 0;
     if (h->variant == 0 && nq > 512) {
         if (split_env >= 0) qpt = split_env;                 // 0 = never split, 1/2/4 = force that many rows per lane
@@ -743,11 +791,10 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
         const int chunk_rows = 256 * qpt;
         const int n_chunks = (nq + chunk_rows - 1) / chunk_rows;
         const size_t n_items = (size_t)n_elig * n_chunks;
-        rc = ensure_dev(q.d_partial, q.d_partial_n, n_items); if (rc) return rc;
         rc = ensure_dev(q.d_dist, q.d_dist_n, n_items * chunk_rows); if (rc) return rc;
         a.q_stride_words = (uint32_t)chunk_rows * LCM_DESC_WORDS;
         a.imp_chunks = (uint32_t)n_chunks; a.imp_chunk_rows = (uint32_t)chunk_rows; a.imp_spi = 1;
-        a.scores = q.d_partial /* per-chunk partial records: unused */; a.keys = q.d_dist; a.keys_stride = (uint32_t)chunk_rows;
+        a.scores = nullptr /* split mode writes no per-chunk records */; a.keys = q.d_dist; a.keys_stride = (uint32_t)chunk_rows;
         hipError_t e = lcm::launch_score_split(a, (uint32_t)n_items, qpt, h->stream);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         lcm::FinalizeArgs f{};
@@ -791,7 +838,7 @@ static int acquire_query_slot(lcm_handle* h, int* ticket) {
     return fail(LCM_ERR_CAPACITY, "%d queries already in flight: collect one first", QUERY_SLOTS);
 }
 
-int lcm_query_submit(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, int* ticket) {
+static int query_submit_impl(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, int* ticket) {
     if (!h || nq < 0 || !ticket || (nq > 0 && !query)) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     *ticket = -1;
     if (nq > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
@@ -810,28 +857,37 @@ int lcm_query_submit(lcm_handle* h, const uint8_t* query, int nq, int query_fram
     }
     rc = enqueue_query(h, q, (const uint32_t*)q.d_query, nq, n_elig); if (rc) return rc;
     q.busy = true;
+    q.db_generation = h->db_generation;
     *ticket = t;
     return LCM_OK;
 }
 
-int lcm_query_collect(lcm_handle* h, int ticket, lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out) {
+static int query_collect_impl(lcm_handle* h, int ticket, lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out) {
     if (!h || !n_out || ticket < 0 || ticket >= QUERY_SLOTS || !h->qslots[ticket].busy) return fail(LCM_ERR_INVALID_ARG, "bad ticket");
     *n_out = 0;
     int rc = set_device(h); if (rc) return rc;
     QuerySlot& q = h->qslots[ticket];
+    if (q.db_generation != h->db_generation) {
+        // the database was cleared / reloaded after the submit: the records describe slots that are gone
+        (void)hipEventSynchronize(q.done);
+        q.busy = false;
+        return fail(LCM_ERR_NOT_FOUND, "ticket %d was submitted before lcm_db_clear / lcm_db_load: its result is void", ticket);
+    }
     HIP_TRY(hipEventSynchronize(q.done));
-    q.busy = false;
-    if (q.n_elig > cap) return fail(LCM_ERR_CAPACITY, "%d score records but room for %d", q.n_elig, cap);
+    // Recoverable argument errors keep the ticket: the finished result can be collected again with enough room.
+    if (q.n_elig > cap) return fail(LCM_ERR_CAPACITY, "%d score records but room for %d (the ticket stays valid)", q.n_elig, cap);
+    if (q.n_elig > 0 && !out_scores) return fail(LCM_ERR_INVALID_ARG, "out_scores is NULL (the ticket stays valid)");
     if (q.n_elig > 0) {
-        if (!out_scores) return fail(LCM_ERR_INVALID_ARG, "out_scores is NULL");
         memcpy(out_scores, q.h_scores, sizeof(lcm_score) * (size_t)q.n_elig);
+        // slots [0, n_elig) existed at submit time and appends only add slots behind them
         if (out_frame_ids) for (int s = 0; s < q.n_elig; ++s) out_frame_ids[s] = h->frames[s].id;
     }
     *n_out = q.n_elig;
+    q.busy = false;
     return LCM_OK;
 }
 
-int lcm_query_scores(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id,
+static int query_scores_impl(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id,
                      lcm_score* out_scores, int32_t* out_frame_ids, int* n_out) {
     if (!h || !n_out) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     *n_out = 0;
@@ -840,7 +896,7 @@ int lcm_query_scores(lcm_handle* h, const uint8_t* query, int nq, int query_fram
     return lcm_query_collect(h, t, out_scores, out_frame_ids, lcm_db_size(h), n_out);
 }
 
-int lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
+static int detect_loops_impl(lcm_handle* h, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
                      lcm_loop_candidate* out, int cap, int* n_out) {
     if (!h || !n_out || cap < 0) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     *n_out = 0;
@@ -865,10 +921,11 @@ int lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, 
                            eligible_prefix(h, current_frame_id, h->params.min_gap));
         if (rc) return rc;
         q.busy = true;
+        q.db_generation = h->db_generation;
     }
     QuerySlot& q = h->qslots[t];
+    q.busy = false;                                  // the ticket never leaves this function, whatever happens below
     HIP_TRY(hipEventSynchronize(q.done));
-    q.busy = false;
     int k = 0, total = 0;
     for (int s = 0; s < q.n_elig; ++s) {
         double sim;
@@ -890,7 +947,7 @@ int lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, 
 
 /* ---- bulk all-vs-all --------------------------------------------------------------------------------- */
 
-int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
+static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
                    const int32_t* q_ids, int n_q_frames, int q_stride_rows,
                    void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets) {
     if (!h || !n_pairs) return fail(LCM_ERR_INVALID_ARG, "bad argument");
@@ -908,10 +965,23 @@ int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_que
     }
     if (q_stride_rows > lcm::MAX_FUSED_QUERY_ROWS && !self) return fail(LCM_ERR_CAPACITY, "query frames may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
 
-    // ---- plan (cached while the database and the query-id list are unchanged)
+    // ---- plan (cached while the database, the query-id list AND the query frames' row counts are unchanged)
+    // The row counts of an external query set live on the device and may change between calls with the same ids, and
+    // they pick the workgroup shape (a stale, smaller maximum would silently skip rows): they are fetched on every
+    // call (n_q_frames * 4 bytes) and are part of the key, as is the stride.
+    std::vector<int32_t> qc;
+    if (!self && n_q_frames > 0) {
+        qc.resize((size_t)n_q_frames);
+        HIP_TRY(hipMemcpyAsync(qc.data(), d_query_counts, sizeof(int32_t) * (size_t)n_q_frames, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int c = 0; c < n_q_frames; ++c)
+            if (qc[c] < 0 || qc[c] > q_stride_rows) return fail(LCM_ERR_INVALID_ARG, "query frame %d has %d rows, stride %d", c, qc[c], q_stride_rows);
+    }
     uint64_t key = mix(mix(mix(0x1234, (uint64_t)h->frames.size()), (uint64_t)n_q_frames), (uint64_t)h->params.min_gap);
-    key = mix(key, self ? 1 : 2);
+    key = mix(mix(key, self ? 1 : 2), (uint64_t)q_stride_rows);
+    key = mix(key, h->db_generation);
     for (int i = 0; i < n_q_frames; ++i) key = mix(key, (uint64_t)(uint32_t)q_ids[i]);
+    for (int32_t c : qc) key = mix(key, (uint64_t)(uint32_t)c);
     if (!h->frames.empty()) key = mix(mix(key, (uint64_t)h->frames.front().id), (uint64_t)h->frames.back().id);
     if (key == 0) key = 1;
     Plan& P = h->plan;
@@ -923,7 +993,7 @@ int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_que
         for (int c = 0; c < n_q_frames; ++c) { P.offsets[c] = total; total += (size_t)eligible_prefix(h, q_ids[c], h->params.min_gap); }
         P.offsets[n_q_frames] = total;
         if (total > 0xFFFFFFFFull) return fail(LCM_ERR_CAPACITY, "more than 2^32 pairs in one call");
-        const int chunk = pick_chunk(total);
+        const int chunk = pick_chunk(h, total);
         P.distances = 0; P.algo_bytes = 0; P.max_q_rows = 0;
         // prefix sums of stored row counts for the distance / byte accounting
         std::vector<uint64_t> pre(h->frames.size() + 1, 0);
@@ -942,12 +1012,8 @@ int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_que
             }
         }
         if (!self) {
-            // row counts of an external query set live on the device: fetch them once per plan
-            std::vector<int32_t> qc((size_t)std::max(n_q_frames, 1));
-            HIP_TRY(hipMemcpy(qc.data(), d_query_counts, sizeof(int32_t) * (size_t)n_q_frames, hipMemcpyDeviceToHost));
             for (int c = 0; c < n_q_frames; ++c) {
                 const int e = (int)(P.offsets[c + 1] - P.offsets[c]);
-                if (qc[c] < 0 || qc[c] > q_stride_rows) return fail(LCM_ERR_INVALID_ARG, "query frame %d has %d rows, stride %d", c, qc[c], q_stride_rows);
                 if (e > 0) {
                     P.distances += (uint64_t)qc[c] * pre[e];
                     P.algo_bytes += pre[e] * 32 + (uint64_t)qc[c] * 32 + 8ull * e;
@@ -999,7 +1065,7 @@ int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_que
 
 // Bulk loop search with the loop test fused on the device: all-vs-all scores stay in device memory, a second tiny
 // kernel applies README.md:123-126 per pair and compacts the candidates; only those cross PCIe.
-int lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
+static int all_vs_all_loops_impl(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
                          const int32_t* q_ids, const int32_t* q_keypoints, int n_q_frames, int q_stride_rows,
                          lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out) {
     if (!h || !n_out) return fail(LCM_ERR_INVALID_ARG, "bad argument");
@@ -1010,6 +1076,7 @@ int lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const int32_t*
     rc = lcm_all_vs_all(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, nullptr, 0, &n_pairs, nullptr);
     if (rc) return rc;
     if (n_pairs_out) *n_pairs_out = n_pairs;
+    h->bulk_scores_valid = 0;
     if (n_pairs == 0) return LCM_OK;
     rc = ensure_dev(h->d_bulk_scores, h->d_bulk_scores_n, n_pairs); if (rc) return rc;
     rc = lcm_all_vs_all(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, h->d_bulk_scores, n_pairs, &n_pairs, nullptr);
@@ -1048,8 +1115,12 @@ int lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const int32_t*
     a.out = h->d_cands; a.counter = d_counter;
     a.n_q = (uint32_t)nq; a.n_pairs = (uint32_t)n_pairs; a.cap = (uint32_t)dev_cap;
     a.min_matches = h->params.min_matches; a.sim_threshold = h->params.sim_threshold;
+    HIP_TRY(hipEventRecord(h->ev_aux_start, h->stream));
     hipError_t e = lcm::launch_loop_test(a, h->stream);
     if (e != hipSuccess) return fail(LCM_ERR_HIP, "loop-test kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(h->ev_aux_stop, h->stream));
+    h->aux_pending = true;
+    h->bulk_scores_valid = n_pairs;
     uint32_t found = 0;
     HIP_TRY(hipMemcpyAsync(&found, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1073,9 +1144,24 @@ int lcm_last_launch_info(const lcm_handle* hc, lcm_launch_info* info) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_stop));
         h->info.kernel_ms = ms;
+        h->info.aux_kernel_ms = 0.0;
         h->info_pending = false;
     }
+    if (h->aux_pending) {
+        HIP_TRY(hipEventSynchronize(h->ev_aux_stop));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev_aux_start, h->ev_aux_stop));
+        h->info.aux_kernel_ms = ms;
+        h->aux_pending = false;
+    }
     *info = h->info;
+    return LCM_OK;
+}
+
+int lcm_last_bulk_scores(const lcm_handle* h, const void** d_scores, size_t* n_records) {
+    if (!h || !d_scores || !n_records) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    *d_scores = h->bulk_scores_valid ? h->d_bulk_scores : nullptr;
+    *n_records = h->bulk_scores_valid;
     return LCM_OK;
 }
 
@@ -1106,6 +1192,51 @@ int lcm_dev_download(lcm_handle* h, void* dst, const void* d_src, size_t bytes) 
     HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return LCM_OK;
+}
+
+/* ---- exported entry points of the functions above, behind the exception guard ----------------------------- */
+
+int lcm_db_reserve(lcm_handle* h, int n_frames, int max_desc) {
+    return guarded([&] { return db_reserve_impl(h, n_frames, max_desc); });
+}
+int lcm_db_append(lcm_handle* h, int frame_id, const uint8_t* desc, int n, int n_keypoints) {
+    return guarded([&] { return db_append_impl(h, frame_id, desc, n, n_keypoints); });
+}
+int lcm_db_append_device(lcm_handle* h, int frame_id, const void* d_desc, int n, int n_keypoints) {
+    return guarded([&] { return db_append_device_impl(h, frame_id, d_desc, n, n_keypoints); });
+}
+int lcm_db_save(lcm_handle* h, const char* path) {
+    return guarded([&] { return db_save_impl(h, path); });
+}
+int lcm_db_load(lcm_handle* h, const char* path) {
+    return guarded([&] { return db_load_impl(h, path); });
+}
+int lcm_match_pair(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt, int32_t* train_idx, uint16_t* dist, int* n_matches) {
+    return guarded([&] { return match_pair_impl(h, query, nq, train, nt, train_idx, dist, n_matches); });
+}
+int lcm_match_features(lcm_handle* h, const uint8_t* query, int nq, const uint8_t* train, int nt, lcm_dmatch* out, int* n_out, int* min_dist) {
+    return guarded([&] { return match_features_impl(h, query, nq, train, nt, out, n_out, min_dist); });
+}
+int lcm_match_stored(lcm_handle* h, int query_frame_id, int train_frame_id, lcm_dmatch* out, int cap, int* n_out, int* min_dist) {
+    return guarded([&] { return match_stored_impl(h, query_frame_id, train_frame_id, out, cap, n_out, min_dist); });
+}
+int lcm_query_submit(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, int* ticket) {
+    return guarded([&] { return query_submit_impl(h, query, nq, query_frame_id, ticket); });
+}
+int lcm_query_collect(lcm_handle* h, int ticket, lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out) {
+    return guarded([&] { return query_collect_impl(h, ticket, out_scores, out_frame_ids, cap, n_out); });
+}
+int lcm_query_scores(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, lcm_score* out_scores, int32_t* out_frame_ids, int* n_out) {
+    return guarded([&] { return query_scores_impl(h, query, nq, query_frame_id, out_scores, out_frame_ids, n_out); });
+}
+int lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, int nq, int n_keypoints, lcm_loop_candidate* out, int cap, int* n_out) {
+    return guarded([&] { return detect_loops_impl(h, current_frame_id, query, nq, n_keypoints, out, cap, n_out); });
+}
+int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids, int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets) {
+    return guarded([&] { return all_vs_all_impl(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, d_scores, scores_cap, n_pairs, pair_offsets); });
+}
+int lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids, const int32_t* q_keypoints, int n_q_frames, int q_stride_rows, lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out) {
+    return guarded([&] { return all_vs_all_loops_impl(h, d_query_rows, d_query_counts, q_ids, q_keypoints, n_q_frames, q_stride_rows, out, cap, n_out, n_pairs_out); });
 }
 
 }  // extern "C"

@@ -24,7 +24,6 @@
 //   wavefront __shfl reduction per query.  Kept for A/B measurement; see DESIGN.md for the numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "lcm_kernels.h"
 
@@ -191,6 +190,9 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
             for (int j = 0; j < QPT; ++j)
                 if (valid(j)) a.keys[out * a.keys_stride + j * THREADS + tid] = best[j];
         }
+        // split mode (per-row best DISTANCES for k_finalize_pairs): this workgroup sees only a chunk of the query
+        // frame, so there is no pair record to form here
+        if (WRITE_KEYS && !ARGMIN) continue;
         // min-of-mins and good-match count: per-lane partials folded with LDS atomics (ds_min_u32 / ds_add_u32), one
         // word per pair parity.  Deliberately not a shuffle tree: this runs once per 4M distances, and the atomics
         // need no extra VGPRs, which keeps the kernel inside the 80-register budget of 6 waves/SIMD without spills.
@@ -383,22 +385,11 @@ __global__ __launch_bounds__(256) void k_score_trainlane(ScoreArgs a) {
     }
 }
 
-// Occupancy throttle: dynamic LDS that the kernel never touches, sized so that exactly `waves_per_simd` workgroups of
-// 256 threads fit a CU's 160 KiB (6 is the measured optimum; the register budget is 80 VGPRs).
-static unsigned lds_pad_bytes() {
-    static int cached = -1;
-    if (cached < 0) {
-        const char* e = getenv("LCM_WAVES_PER_SIMD");      // tuning knob; default below
-        int w = e ? atoi(e) : 6;
-        cached = (w >= 1 && w <= 7) ? (int)((160 * 1024) / w - 512) & ~255 : 0;
-    }
-    return (unsigned)cached;
-}
-
 template <int THREADS, int QPT>
 static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool write_keys, bool argmin, hipStream_t st) {
     if (n_items == 0) return hipSuccess;
-    const unsigned lds = (THREADS == 256 && QPT == 8) ? lds_pad_bytes() : 0;
+    // 78-80 VGPRs (QPT = 8) => 6 waves per SIMD by the register file alone: no other occupancy control is needed
+    const unsigned lds = 0;
     if (write_keys && argmin)
         hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true, true>), dim3(n_items), dim3(THREADS), lds, st, a);
     else if (write_keys)

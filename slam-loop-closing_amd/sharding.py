@@ -48,6 +48,18 @@ def offsets_from_counts(counts: np.ndarray) -> np.ndarray:
     return offs
 
 
+def shard_destinations(ids: Sequence[int], gap: int, rank: int, world: int) -> np.ndarray:
+    """For every record of rank `rank`'s (query asc, owned stored asc) array: its index in the single-device
+    (query asc, stored asc) array.  Query c's k-th owned frame is stored position rank + k*world."""
+    e = eligible_counts(ids, gap)
+    offs = offsets_from_counts(e)
+    er = np.maximum(0, (e - rank + world - 1) // world)
+    offr = offsets_from_counts(er)
+    c_of = np.repeat(np.arange(len(e)), er)
+    k_of = np.arange(int(offr[-1])) - offr[c_of]
+    return offs[c_of] + rank + k_of * world
+
+
 def merge_shard_scores(shard_scores: List[np.ndarray], ids: Sequence[int], gap: int) -> Tuple[np.ndarray, np.ndarray]:
     """Un-permute per-rank score arrays (each in (query asc, owned stored asc) order) into the single-device
     (query asc, stored asc) order.  Returns (scores, offsets[n_frames + 1])."""
@@ -55,19 +67,13 @@ def merge_shard_scores(shard_scores: List[np.ndarray], ids: Sequence[int], gap: 
     e = eligible_counts(ids, gap)
     offs = offsets_from_counts(e)
     out = np.zeros(int(offs[-1]), SCORE_DTYPE)
-    n = len(e)
     for r in range(world):
-        er = np.maximum(0, (e - r + world - 1) // world)
-        offr = offsets_from_counts(er)
+        dst = shard_destinations(ids, gap, r, world)
         src = np.asarray(shard_scores[r])
-        if int(offr[-1]) != src.shape[0]:
-            raise ValueError(f"rank {r}: expected {int(offr[-1])} score records, got {src.shape[0]}")
-        if src.shape[0] == 0:
-            continue
-        # destination index of every record of this shard, vectorised: for query c, k-th owned -> offs[c] + r + k*W
-        c_of = np.repeat(np.arange(n), er)
-        k_of = np.arange(src.shape[0]) - offr[c_of]
-        out[offs[c_of] + r + k_of * world] = src
+        if dst.shape[0] != src.shape[0]:
+            raise ValueError(f"rank {r}: expected {dst.shape[0]} score records, got {src.shape[0]}")
+        if src.shape[0]:
+            out[dst] = src
     return out, offs
 
 

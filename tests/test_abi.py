@@ -110,6 +110,8 @@ def test_null_handle_calls_fail_cleanly(pkg):
     assert lib.lcm_all_vs_all_loops(None, None, None, None, None, 0, 0, None, 0, C.byref(z), C.byref(z)) == -1
     assert lib.lcm_last_launch_info(None, C.byref(info)) == -1
     assert lib.lcm_set_kernel_variant(None, 0) == -1
+    assert lib.lcm_set_tuning(None, 0, 0) == -1
+    assert lib.lcm_last_bulk_scores(None, C.byref(C.c_void_p()), C.byref(z)) == -1
     assert lib.lcm_dev_alloc(None, 16, C.byref(C.c_void_p())) == -1
     assert lib.lcm_dev_free(None, None) == -1
     assert lib.lcm_dev_upload(None, None, None, 0) == -1

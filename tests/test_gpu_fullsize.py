@@ -146,18 +146,15 @@ def test_cfg2_full_database_sampled_vs_oracle_and_sharded(matcher, oracle, pkg):
         matcher.clear()
 
 
-def test_search_larger_than_one_launch(pkg, oracle, monkeypatch):
+def test_search_larger_than_one_launch(pkg, oracle):
     """More than 2^20 work items: the bulk search goes out as several launches; the records must not notice."""
     fs = pkg.synth.make_frames(1500, 256, seed=11)
     p = pkg.default_params()
     p.min_gap = 30
 
     def run(chunk):
-        if chunk:
-            monkeypatch.setenv("LCM_CHUNK", str(chunk))
-        else:
-            monkeypatch.delenv("LCM_CHUNK", raising=False)
         with pkg.Matcher(p) as m:
+            m.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, chunk)               # 0 = automatic
             for f in range(fs.n_frames):
                 m.append(int(fs.ids[f]), fs.frame(f))
             n, offs = m.all_vs_all_plan()

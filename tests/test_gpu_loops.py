@@ -315,7 +315,7 @@ def test_fused_on_device_loop_test(matcher, oracle, pkg):
 def test_short_database_split_mode_all_regimes(matcher, oracle, pkg):
     """lcm_query_scores cuts a pair's query rows over 8 / 4 / 2 / 1 workgroups depending on how many stored frames are
     eligible (< 256: 8 pieces, < 3072: 4, < 6144: 2, more: 1).  Every regime must give the single-workgroup answer
-    (LCM_SPLIT=0 forces the unsplit path; the full-size sharded test covers it through lcm_all_vs_all)."""
+    (lcm_set_tuning(LCM_TUNE_ONLINE_SPLIT, 0) forces the unsplit path; the full-size sharded test covers it through lcm_all_vs_all)."""
     fs = pkg.synth.make_frames(700, 600, seed=57, ragged=True, dup_frac=0.2)
     fs.counts[50] = 0
     gap = 1

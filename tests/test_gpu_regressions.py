@@ -1,0 +1,138 @@
+"""One GPU test per defect found in review (round-1 VERDICT "What's weak" 7/8, ADVICE medium findings): each fails on
+the code as it was and pins the repaired behaviour."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bulk(m, pkg, d_rows, d_counts, ids, stride):
+    n, offs = m.all_vs_all_plan(d_rows, d_counts, ids, stride)
+    d_scores = m.dev_alloc(max(n, 1) * 8)
+    try:
+        assert m.all_vs_all(d_scores, n, d_rows, d_counts, ids, stride) == n
+        out = np.zeros(max(n, 1), pkg.capi.SCORE_DTYPE)
+        m.sync()
+        m.dev_download(d_scores, out)
+    finally:
+        m.dev_free(d_scores)
+    return out[:n], offs, m.launch_info()
+
+
+def test_plan_is_not_stale_when_external_query_counts_change(matcher, oracle, pkg):
+    """Same query ids, same buffers, new device-side row counts: the cached plan used to keep the old maximum row
+    count, launch the 64-thread workgroup shape and silently score only the first 512 rows of every query frame."""
+    fs = pkg.synth.make_frames(12, 2000, seed=91, dup_frac=0.3)
+    gap = 2
+    matcher.set_params(min_gap=gap)
+    p = oracle.default_params(min_gap=gap)
+    d_rows = matcher.dev_alloc(fs.rows.nbytes)
+    d_counts = matcher.dev_alloc(fs.counts.nbytes)
+    try:
+        matcher.clear()
+        for f in range(fs.n_frames):
+            matcher.append(int(fs.ids[f]), fs.frame(f))
+        matcher.dev_upload(d_rows, fs.rows)
+        infos = []
+        for counts in (np.full(fs.n_frames, 400, np.int32), fs.counts.copy(), np.full(fs.n_frames, 1100, np.int32)):
+            matcher.dev_upload(d_counts, counts)
+            got, offs, info = _bulk(matcher, pkg, d_rows, d_counts, fs.ids, fs.stride_rows)
+            k = 0
+            for c in range(fs.n_frames):
+                for i in range(fs.n_frames):
+                    if fs.ids[c] - fs.ids[i] >= gap:
+                        assert got[k] == oracle.pair_score(fs.rows[c, : counts[c]], fs.frame(i), p), (c, i, counts[c])
+                        k += 1
+            assert k == len(got)
+            infos.append(int(info.distances))
+        assert infos[0] * 5 == infos[1] == pytest.approx(infos[2] * 2000 / 1100)      # the accounting follows too
+    finally:
+        matcher.dev_free(d_rows); matcher.dev_free(d_counts)
+        matcher.set_params(min_gap=30)
+        matcher.clear()
+
+
+def test_collect_with_too_small_buffer_keeps_the_ticket(matcher, oracle, pkg):
+    fs = pkg.synth.make_frames(20, 300, seed=5)
+    matcher.set_params(min_gap=1)
+    try:
+        matcher.clear()
+        for f in range(fs.n_frames):
+            matcher.append(int(fs.ids[f]), fs.frame(f))
+        q = pkg.synth.make_frames(1, 300, seed=6).frame(0)
+        t = matcher.query_submit(q, 100)
+        with pytest.raises(pkg.LcmError) as e:
+            matcher.query_collect(t, cap=5)                      # 20 records, room for 5
+        assert e.value.code == -4
+        scores, ids = matcher.query_collect(t, cap=20)           # the finished result is still there
+        assert ids.tolist() == fs.ids.tolist()
+        want = [oracle.pair_score(q, fs.frame(i), oracle.default_params(min_gap=1)) for i in range(fs.n_frames)]
+        assert list(scores) == want
+        with pytest.raises(pkg.LcmError) as e:
+            matcher.query_collect(t, cap=20)                     # ... and now it is consumed
+        assert e.value.code == -1
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
+
+
+def test_submit_then_clear_then_collect_is_refused(matcher, pkg):
+    """A ticket submitted before lcm_db_clear used to index the emptied frame list at collect time."""
+    fs = pkg.synth.make_frames(16, 200, seed=8)
+    matcher.set_params(min_gap=1)
+    try:
+        matcher.clear()
+        for f in range(fs.n_frames):
+            matcher.append(int(fs.ids[f]), fs.frame(f))
+        tickets = [matcher.query_submit(fs.frame(3), 50 + k) for k in range(4)]
+        matcher.clear()
+        matcher.append(1000, fs.frame(0))                        # a different database behind the same handle
+        for t in tickets:
+            with pytest.raises(pkg.LcmError) as e:
+                matcher.query_collect(t, cap=64)
+            assert e.value.code == -6                            # LCM_ERR_NOT_FOUND: the result is void
+        # all four slots are free again and the new database answers
+        t = [matcher.query_submit(fs.frame(3), 2000 + k) for k in range(4)]
+        for x in t:
+            scores, ids = matcher.query_collect(x)
+            assert ids.tolist() == [1000] and len(scores) == 1
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
+
+
+def test_db_load_rejects_a_lying_header_and_keeps_the_old_database(matcher, pkg, tmp_path):
+    """n_frames = 0xFFFFFFFF used to reach std::vector::resize (a ~50 GB allocation / std::bad_alloc across the C ABI);
+    a bad file also used to cost the caller the frames already stored."""
+    fs = pkg.synth.make_frames(5, 100, seed=2)
+    try:
+        matcher.clear()
+        for f in range(fs.n_frames):
+            matcher.append(int(fs.ids[f]), fs.frame(f))
+        good = str(tmp_path / "good.lcmdb")
+        matcher.save(good)
+        blob = open(good, "rb").read()
+        cases = {
+            "huge_n_frames": blob[:12] + struct.pack("<I", 0xFFFFFFFF) + blob[16:],
+            "n_frames_beyond_file": blob[:12] + struct.pack("<I", 100000) + blob[16:],
+            "negative_int_n_frames": blob[:12] + struct.pack("<I", 0x80000001) + blob[16:],
+            "rows_beyond_file": blob[: len(blob) - 64],
+            "row_count_above_max": blob[:24] + blob[24:28] + struct.pack("<i", 60000) + blob[32:],
+            "ids_not_increasing": blob[:24] + struct.pack("<i", 7) + blob[28:36] + struct.pack("<i", 7) + blob[40:],
+        }
+        for name, data in cases.items():
+            bad = str(tmp_path / (name + ".lcmdb"))
+            open(bad, "wb").write(data)
+            with pytest.raises(pkg.LcmError) as e:
+                matcher.load(bad)
+            assert e.value.code == -1, name
+            assert len(matcher) == fs.n_frames, name             # rejected BEFORE the old contents were dropped
+            np.testing.assert_array_equal(matcher.read_frame(4), fs.frame(4))
+        matcher.load(good)
+        assert len(matcher) == fs.n_frames
+        np.testing.assert_array_equal(matcher.read_frame(2), fs.frame(2))
+    finally:
+        matcher.clear()
