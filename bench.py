@@ -167,9 +167,10 @@ def cfg4_fused_extra(pkg, torch, dev, local_rank, gap):
     for f in range(n_frames):
         m.append_device(int(fs.ids[f]), d_rows.data_ptr() + f * fb, int(fs.counts[f]))
     m.sync()
+    buf = np.zeros(pkg.synth.n_pairs_all_vs_all(n_frames, gap), pkg.capi.CANDIDATE_DTYPE)   # worst case: every pair
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    cands, pairs = m.all_vs_all_loops(cap=1 << 21)
+    cands, pairs = m.all_vs_all_loops(out=buf)
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     info = m.launch_info()
@@ -303,11 +304,12 @@ def main():
         lens = [n_local]
 
     fused_out = {}
+    fused_buf = np.zeros(max(n_local, 1), pkg.capi.CANDIDATE_DTYPE) if fused else None     # worst case: every pair
 
     def step():
         if fused:
             # lcm_all_vs_all_loops: score kernel -> scores stay in HBM -> k_loop_test -> compacted candidates -> host
-            fused_out["cands"], fused_out["pairs"] = m.all_vs_all_loops(cap=1 << 21, **q_args)
+            fused_out["cands"], fused_out["pairs"] = m.all_vs_all_loops(out=fused_buf, **q_args)
         elif not multi:
             m.all_vs_all(scores.data_ptr(), n_local, **q_args)
         else:

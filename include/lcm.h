@@ -189,6 +189,14 @@ LCM_API int  lcm_loop_test(const lcm_params* p, const lcm_score* s, int n_query_
 LCM_API int  lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
                             const int32_t* q_ids, int n_q_frames, int q_stride_rows,
                             void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets);
+/* Same search through the ARGMIN kernel: besides every query row's best distance it finds the FIRST train row that
+ * attains it (BFMatcher's trainIdx) — "per-query min/argmin" of BASELINE.json's north_star — and makes the indices
+ * observable without 8 KB of keys per pair: d_index_sums (device, one uint32 per pair, same order as d_scores)
+ * receives the sum mod 2^32 of the train indices of the pair's GOOD matches (0 for an empty pair). */
+LCM_API int  lcm_all_vs_all_argmin(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
+                                   const int32_t* q_ids, int n_q_frames, int q_stride_rows,
+                                   void* d_scores, size_t scores_cap, void* d_index_sums,
+                                   size_t* n_pairs, size_t* pair_offsets);
 /* Same search with the loop test fused on the device (README.md:123-126; BASELINE.json configs[3]): scores never
  * leave HBM, a second kernel applies similarity > threshold && good >= min_matches per pair in IEEE double and
  * compacts the candidates; `out` (host) receives them sorted by (current_frame_id, matched_frame_id).
@@ -203,8 +211,9 @@ LCM_API int  lcm_last_launch_info(const lcm_handle* h, lcm_launch_info* info);
 LCM_API int  lcm_last_bulk_scores(const lcm_handle* h, const void** d_scores, size_t* n_records);
 
 /* Select the kernel variant of the bulk / online scoring (A/B measurement; results are identical):
- * 0 = query-row-per-lane, distances only (default); 1 = same, tracking (dist, idx) keys; 2 / 3 = the
- * train-row-per-lane mapping with LDS-staged queries and wavefront shuffle reductions, distances only / keys. */
+ * 0 = query-row-per-lane, best distance per query row; 1 = same + the first train row attaining it (argmin, by
+ * 16-row group keys and a re-scan of the winning group); 2 / 3 = the train-row-per-lane mapping with LDS-staged
+ * queries and wavefront shuffle reductions, distances only / (dist, idx) keys. */
 LCM_API int  lcm_set_kernel_variant(lcm_handle* h, int variant);
 
 /* Measurement knobs (defaults are the measured optima; results never depend on them):

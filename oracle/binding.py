@@ -61,6 +61,9 @@ def lib():
         L.orc_fast_score_pairs.restype = C.c_double
         L.orc_fast_score_pairs.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_size_t, C.POINTER(OrcParams), C.c_int,
                                            _vp, C.c_char_p]
+        L.orc_fast_score_pairs_idx.restype = C.c_double
+        L.orc_fast_score_pairs_idx.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_size_t, C.POINTER(OrcParams), C.c_int,
+                                               _vp, _vp, C.c_char_p]
         _lib = L
     return _lib
 
@@ -168,3 +171,24 @@ def fast_score_pairs(rows, counts, pair_q, pair_t, params=None, n_threads=1):
     secs = lib().orc_fast_score_pairs(_p(rows), _p(counts), rows.shape[1], _p(pq), _p(pt), pq.shape[0], C.byref(p),
                                       n_threads, scores.ctypes.data_as(_vp), isa)
     return scores[: pq.shape[0]], secs, isa.value.decode()
+
+
+def fast_score_pairs_idx(rows, counts, pair_q, pair_t, params=None, n_threads=1):
+    """Tuned path + the per-pair checksum of the good matches' train indices: (scores, idx_sums uint32)."""
+    rows = np.ascontiguousarray(rows, np.uint8)
+    counts = np.ascontiguousarray(counts, np.int32)
+    pq = np.ascontiguousarray(pair_q, np.int32)
+    pt = np.ascontiguousarray(pair_t, np.int32)
+    p = params or default_params()
+    scores = np.zeros(max(pq.shape[0], 1), SCORE_DTYPE)
+    sums = np.zeros(max(pq.shape[0], 1), np.uint32)
+    isa = C.create_string_buffer(64)
+    lib().orc_fast_score_pairs_idx(_p(rows), _p(counts), rows.shape[1], _p(pq), _p(pt), pq.shape[0], C.byref(p),
+                                   n_threads, scores.ctypes.data_as(_vp), sums.ctypes.data_as(_vp), isa)
+    return scores[: pq.shape[0]], sums[: pq.shape[0]]
+
+
+def index_sum(q, t, params=None) -> int:
+    """The same checksum from the SCALAR oracle's matchFeatures: sum of trainIdx over the good matches mod 2^32."""
+    m, _ = match_features(q, t, params)
+    return int(m["train_idx"].astype(np.uint64).sum() % (1 << 32))

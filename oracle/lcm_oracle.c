@@ -245,6 +245,7 @@ typedef struct fast_job {
     const int32_t* pair_q; const int32_t* pair_t; size_t n_pairs;
     const orc_params* p; orc_score* scores;
     int tid, n_threads, use_avx512, max_rows;
+    uint32_t* idx_sums;   /* optional: per pair, sum of the GOOD matches' train indices mod 2^32 */
 } fast_job;
 
 static void* fast_worker(void* arg) {
@@ -255,6 +256,7 @@ static void* fast_worker(void* arg) {
         int nq = jb->counts[qi], nt = jb->counts[ti];
         orc_score* s = &jb->scores[k];
         s->n_train = (uint16_t)nt;
+        if (jb->idx_sums) jb->idx_sums[k] = 0;
         if (nq <= 0 || nt <= 0) { s->good_count = 0; s->min_dist = 0xFFFF; continue; }
         const uint8_t* q = jb->rows + (size_t)qi * jb->stride_rows * 32;
         const uint8_t* t = jb->rows + (size_t)ti * jb->stride_rows * 32;
@@ -266,18 +268,30 @@ static void* fast_worker(void* arg) {
         for (int i = 0; i < nq; ++i) { uint32_t d = (uint32_t)(keys[i] >> 32); if (d < m) m = d; }
         uint32_t thr = (uint32_t)jb->p->ratio * m;
         if ((uint32_t)jb->p->dist_floor > thr) thr = (uint32_t)jb->p->dist_floor;
-        uint32_t good = 0;
-        for (int i = 0; i < nq; ++i) good += ((uint32_t)(keys[i] >> 32) <= thr);
+        uint32_t good = 0, isum = 0;
+        for (int i = 0; i < nq; ++i) {
+            const int ok = ((uint32_t)(keys[i] >> 32) <= thr);
+            good += (uint32_t)ok;
+            if (ok) isum += (uint32_t)keys[i];      /* low word of the key = trainIdx of the first minimum */
+        }
         s->good_count = good;
         s->min_dist = (uint16_t)m;
+        if (jb->idx_sums) jb->idx_sums[k] = isum;
     }
     free(keys);
     return NULL;
 }
 
+double orc_fast_score_pairs_idx(const uint8_t* rows, const int32_t* counts, int stride_rows, const int32_t* pair_q, const int32_t* pair_t, size_t n_pairs, const orc_params* p, int n_threads, orc_score* scores, uint32_t* idx_sums, char* isa_out);
 double orc_fast_score_pairs(const uint8_t* rows, const int32_t* counts, int stride_rows,
                             const int32_t* pair_q, const int32_t* pair_t, size_t n_pairs,
                             const orc_params* p, int n_threads, orc_score* scores, char* isa_out) {
+    return orc_fast_score_pairs_idx(rows, counts, stride_rows, pair_q, pair_t, n_pairs, p, n_threads, scores, NULL, isa_out);
+}
+
+double orc_fast_score_pairs_idx(const uint8_t* rows, const int32_t* counts, int stride_rows,
+                                const int32_t* pair_q, const int32_t* pair_t, size_t n_pairs,
+                                const orc_params* p, int n_threads, orc_score* scores, uint32_t* idx_sums, char* isa_out) {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     int use512 = have_avx512_vpopcnt();
@@ -287,7 +301,7 @@ double orc_fast_score_pairs(const uint8_t* rows, const int32_t* counts, int stri
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int i = 0; i < n_threads; ++i) {
-        fast_job jb = { rows, counts, stride_rows, pair_q, pair_t, n_pairs, p, scores, i, n_threads, use512, stride_rows };
+        fast_job jb = { rows, counts, stride_rows, pair_q, pair_t, n_pairs, p, scores, i, n_threads, use512, stride_rows, idx_sums };
         jobs[i] = jb;
         if (i > 0) pthread_create(&th[i], NULL, fast_worker, &jobs[i]);
     }

@@ -80,6 +80,12 @@ double orc_fast_score_pairs(const uint8_t* rows, const int32_t* counts, int stri
                             const int32_t* pair_q, const int32_t* pair_t, size_t n_pairs,
                             const orc_params* p, int n_threads, orc_score* scores, char* isa_out);
 
+/* Same, also returning per pair the sum mod 2^32 of the train indices (DMatch::trainIdx, first minimum) of the GOOD
+ * matches — the checksum lcm_all_vs_all_argmin produces on the device.  idx_sums may be NULL. */
+double orc_fast_score_pairs_idx(const uint8_t* rows, const int32_t* counts, int stride_rows,
+                                const int32_t* pair_q, const int32_t* pair_t, size_t n_pairs,
+                                const orc_params* p, int n_threads, orc_score* scores, uint32_t* idx_sums, char* isa_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,8 @@ _SIGNATURES = {
     "lcm_loop_test": (C.c_int, [C.POINTER(Params), C.POINTER(Score), C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lcm_all_vs_all": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
                                   C.POINTER(C.c_size_t), _vp]),
+    "lcm_all_vs_all_argmin": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp,
+                                         C.POINTER(C.c_size_t), _vp]),
     "lcm_all_vs_all_loops": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lcm_last_launch_info": (C.c_int, [_vp, C.POINTER(LaunchInfo)]),
@@ -336,14 +338,31 @@ class Matcher:
                                         _vp(d_scores), scores_cap, C.byref(n), None))
         return n.value
 
+    def all_vs_all_argmin(self, d_scores: int, scores_cap: int, d_index_sums: int, d_query_rows: int = 0,
+                          d_query_counts: int = 0, q_ids: Optional[Sequence[int]] = None, q_stride_rows: int = 0) -> int:
+        """all_vs_all through the argmin kernel; d_index_sums receives one uint32 per pair (sum of the good matches'
+        train indices mod 2^32)."""
+        ids = None if q_ids is None else np.ascontiguousarray(q_ids, np.int32)
+        nq = len(self) if ids is None else ids.shape[0]
+        n = C.c_size_t(0)
+        _check(self._lib.lcm_all_vs_all_argmin(self._h, _vp(d_query_rows) if d_query_rows else None,
+                                               _vp(d_query_counts) if d_query_counts else None, _ptr(ids), nq,
+                                               q_stride_rows, _vp(d_scores), scores_cap, _vp(d_index_sums),
+                                               C.byref(n), None))
+        return n.value
+
     def all_vs_all_loops(self, cap: int = 1 << 20, d_query_rows: int = 0, d_query_counts: int = 0,
                          q_ids: Optional[Sequence[int]] = None, q_keypoints: Optional[Sequence[int]] = None,
-                         q_stride_rows: int = 0) -> Tuple[np.ndarray, int]:
+                         q_stride_rows: int = 0, out: Optional[np.ndarray] = None) -> Tuple[np.ndarray, int]:
         """Bulk loop search with the loop test fused on the device: (candidates sorted by (current, matched), n_pairs)."""
         ids = None if q_ids is None else np.ascontiguousarray(q_ids, np.int32)
         kps = None if q_keypoints is None else np.ascontiguousarray(q_keypoints, np.int32)
         nq = len(self) if ids is None else ids.shape[0]
-        out = np.zeros(max(cap, 1), CANDIDATE_DTYPE)
+        if out is None:
+            out = np.zeros(max(cap, 1), CANDIDATE_DTYPE)
+        else:
+            assert out.dtype == CANDIDATE_DTYPE and out.flags["C_CONTIGUOUS"]
+            cap = len(out)
         n, npairs = C.c_size_t(0), C.c_size_t(0)
         _check(self._lib.lcm_all_vs_all_loops(self._h, _vp(d_query_rows) if d_query_rows else None,
                                               _vp(d_query_counts) if d_query_counts else None, _ptr(ids), _ptr(kps), nq,

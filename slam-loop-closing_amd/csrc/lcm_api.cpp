@@ -949,7 +949,8 @@ static int detect_loops_impl(lcm_handle* h, int current_frame_id, const uint8_t*
 
 static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
                    const int32_t* q_ids, int n_q_frames, int q_stride_rows,
-                   void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets) {
+                   void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets,
+                   uint32_t* d_idx_sums = nullptr) {
     if (!h || !n_pairs) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     int rc = set_device(h); if (rc) return rc;
     const bool self = (d_query_rows == nullptr);
@@ -1043,7 +1044,9 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     a.q_stride_words = (uint32_t)q_stride_rows * LCM_DESC_WORDS;
     a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
     a.items = P.d_items; a.scores = d_scores; a.keys = nullptr; a.keys_stride = 0;
+    a.idx_sums = d_idx_sums;             // non-NULL: the argmin kernel (variant 1) runs whatever the handle's variant
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
+    const int variant = d_idx_sums ? 1 : h->variant;
     // Very large searches go out as several launches (<= 2^20 work items, a few seconds each): no single kernel runs
     // long enough to meet a compute-queue timeout, and the stream stays responsive.
     constexpr size_t MAX_ITEMS_PER_LAUNCH = 1u << 20;
@@ -1052,7 +1055,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     for (size_t first = 0; first < P.items.size(); first += MAX_ITEMS_PER_LAUNCH) {
         const uint32_t n = (uint32_t)std::min(MAX_ITEMS_PER_LAUNCH, P.items.size() - first);
         a.items = P.d_items + first;
-        hipError_t e = lcm::launch_score(a, n, P.max_q_rows, false, h->variant, h->stream);
+        hipError_t e = lcm::launch_score(a, n, P.max_q_rows, false, variant, h->stream);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         ++launches; biggest = std::max(biggest, n);
     }
@@ -1102,7 +1105,8 @@ static int all_vs_all_loops_impl(lcm_handle* h, const void* d_query_rows, const 
         m_qkp[c] = self ? h->frames[c].n_kp : (q_keypoints ? q_keypoints[c] : qc[c]);
     }
     for (int s = 0; s < ns; ++s) { m_did[s] = h->frames[s].id; m_dkp[s] = h->frames[s].n_kp; }
-    rc = ensure_dev(h->d_meta, h->d_meta_n, meta.size() + 4); if (rc) return rc;
+    const size_t n_blocks = (n_pairs + 255) / 256;
+    rc = ensure_dev(h->d_meta, h->d_meta_n, meta.size() + 4 + n_blocks); if (rc) return rc;
     const size_t dev_cap = std::max<size_t>(std::min<size_t>(cap, n_pairs), 1);
     rc = ensure_dev(h->d_cands, h->d_cands_n, dev_cap); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->d_meta, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice, h->stream));
@@ -1113,6 +1117,7 @@ static int all_vs_all_loops_impl(lcm_handle* h, const void* d_query_rows, const 
     a.offsets = reinterpret_cast<const uint32_t*>(h->d_meta);
     a.q_ids = h->d_meta + (nq + 1); a.q_kp = a.q_ids + nq; a.db_ids = a.q_kp + nq; a.db_kp = a.db_ids + ns;
     a.out = h->d_cands; a.counter = d_counter;
+    a.block_counts = d_counter + 4;
     a.n_q = (uint32_t)nq; a.n_pairs = (uint32_t)n_pairs; a.cap = (uint32_t)dev_cap;
     a.min_matches = h->params.min_matches; a.sim_threshold = h->params.sim_threshold;
     HIP_TRY(hipEventRecord(h->ev_aux_start, h->stream));
@@ -1126,13 +1131,8 @@ static int all_vs_all_loops_impl(lcm_handle* h, const void* d_query_rows, const 
     HIP_TRY(hipStreamSynchronize(h->stream));
     *n_out = found;
     if (found > cap || !out) return found ? fail(LCM_ERR_CAPACITY, "%u loop candidates but room for %zu", found, cap) : LCM_OK;
-    if (found) {
-        HIP_TRY(hipMemcpy(out, h->d_cands, sizeof(lcm_loop_candidate) * found, hipMemcpyDeviceToHost));
-        std::sort(out, out + found, [](const lcm_loop_candidate& x, const lcm_loop_candidate& y) {
-            return x.current_frame_id != y.current_frame_id ? x.current_frame_id < y.current_frame_id
-                                                            : x.matched_frame_id < y.matched_frame_id;
-        });
-    }
+    // the device compacted them in pair order = (current id, matched id) ascending: nothing to sort
+    if (found) HIP_TRY(hipMemcpy(out, h->d_cands, sizeof(lcm_loop_candidate) * found, hipMemcpyDeviceToHost));
     return LCM_OK;
 }
 
@@ -1234,6 +1234,10 @@ int lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, 
 }
 int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids, int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets) {
     return guarded([&] { return all_vs_all_impl(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, d_scores, scores_cap, n_pairs, pair_offsets); });
+}
+int lcm_all_vs_all_argmin(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids, int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, void* d_index_sums, size_t* n_pairs, size_t* pair_offsets) {
+    if (d_scores && !d_index_sums) return fail(LCM_ERR_INVALID_ARG, "d_index_sums is NULL");
+    return guarded([&] { return all_vs_all_impl(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, d_scores, scores_cap, n_pairs, pair_offsets, (uint32_t*)d_index_sums); });
 }
 int lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids, const int32_t* q_keypoints, int n_q_frames, int q_stride_rows, lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out) {
     return guarded([&] { return all_vs_all_loops_impl(h, d_query_rows, d_query_counts, q_ids, q_keypoints, n_q_frames, q_stride_rows, out, cap, n_out, n_pairs_out); });

@@ -29,6 +29,7 @@ struct ScoreArgs {
     void*           scores;      // lcm_score records (8 bytes each)
     uint32_t*       keys;        // optional: best packed key per query row, keys[pair * keys_stride + row]
     uint32_t        keys_stride;
+    uint32_t*       idx_sums;    // optional (ARGMIN kernels): per pair, sum of the train indices of its GOOD matches mod 2^32
     int32_t         ratio;
     int32_t         dist_floor;
     // Implicit items (items == NULL): ONE query frame of imp_nq rows at q_rows, cut into imp_chunks chunks of
@@ -60,7 +61,8 @@ hipError_t launch_finalize(const FinalizeArgs& a, uint32_t n_pairs, hipStream_t 
 // On-device loop test over a finished score array (BASELINE.json configs[3] "fused on-device filter + loop test"):
 // pair p belongs to query frame c = upper_bound(offsets, p) - 1 and stored slot p - offsets[c]; a candidate is
 // similarity = good / min(kp_q, kp_t) > sim_threshold (IEEE double, strict) and good >= min_matches.  Candidates
-// are appended through an atomic counter (order restored on the host: (current id, matched id) is a total order).
+// are compacted in pair order (count per 256-pair block, prefix scan, emit), which is (current id, matched id)
+// ascending: the host does not sort.
 struct LoopTestArgs {
     const void*     scores;        // lcm_score records
     const uint32_t* offsets;       // n_q + 1 pair offsets per query frame
@@ -70,6 +72,7 @@ struct LoopTestArgs {
     const int32_t*  db_kp;
     void*           out;           // lcm_loop_candidate records (24 bytes)
     uint32_t*       counter;       // number of candidates found (may exceed cap: count only)
+    uint32_t*       block_counts;  // scratch: ceil(n_pairs / 256) words (candidates per block, then their prefix)
     uint32_t        n_q, n_pairs, cap;
     int32_t         min_matches;
     double          sim_threshold;

@@ -100,18 +100,67 @@ __device__ __forceinline__ void fold2_min(uint32_t& best, const uint32_t (&q)[8]
           "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
 }
 
+// Re-scan step (ARGMIN kernels): the distance between this lane's query row and ONE train row that the lane picks
+// itself (byte offset `off` from the wave-uniform frame base).  Hand-written so that it needs exactly 5 temporary
+// VGPRs: the 64 registers holding the query rows stay where they are (the compiler's own version of this loop wants
+// 157 VGPRs and spills the query rows of the main loop).
+__device__ __forceinline__ uint32_t rescan_distance(const uint32_t (&q)[8], const uint32_t* base, uint32_t off) {
+    uint32_t d, t0, t1, t2, t3;
+    asm volatile(
+        "global_load_dword %1, %5, %6\n\t"
+        "global_load_dword %2, %5, %6 offset:4\n\t"
+        "global_load_dword %3, %5, %6 offset:8\n\t"
+        "global_load_dword %4, %5, %6 offset:12\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_xor_b32_e32 %1, %7, %1\n\tv_bcnt_u32_b32 %0, %1, 0\n\t"
+        "v_xor_b32_e32 %2, %8, %2\n\tv_bcnt_u32_b32 %0, %2, %0\n\t"
+        "v_xor_b32_e32 %3, %9, %3\n\tv_bcnt_u32_b32 %0, %3, %0\n\t"
+        "v_xor_b32_e32 %4, %10, %4\n\tv_bcnt_u32_b32 %0, %4, %0\n\t"
+        "global_load_dword %1, %5, %6 offset:16\n\t"
+        "global_load_dword %2, %5, %6 offset:20\n\t"
+        "global_load_dword %3, %5, %6 offset:24\n\t"
+        "global_load_dword %4, %5, %6 offset:28\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_xor_b32_e32 %1, %11, %1\n\tv_bcnt_u32_b32 %0, %1, %0\n\t"
+        "v_xor_b32_e32 %2, %12, %2\n\tv_bcnt_u32_b32 %0, %2, %0\n\t"
+        "v_xor_b32_e32 %3, %13, %3\n\tv_bcnt_u32_b32 %0, %3, %0\n\t"
+        "v_xor_b32_e32 %4, %14, %4\n\tv_bcnt_u32_b32 %0, %4, %0"
+        : "=&v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(off), "s"(base), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7])
+        : "memory");
+    return d;
+}
+
 // ---------------------------------------------------------------------------------------------------
-// Variant 0: row-per-lane.  ARGMIN = true tracks (dist, train index) keys; false tracks distances only.
+// Variants 0 / 1: row-per-lane.  ARGMIN = false tracks the best DISTANCE per query row; ARGMIN = true also finds the
+// FIRST train row that attains it (cv::BFMatcher's strict-'<' ascending scan) at the same inner-loop cost:
+//
+//   * the inner loop is the distance-only one in both cases (fold2_min: 16 x (v_xor, s_nop, v_bcnt) + v_min3 per
+//     two train rows) — no index arithmetic per distance;
+//   * every ARGMIN_GROUP (16) train rows, each lane folds `running_min << 22 | group` into a PRIVATE LDS word per
+//     query row with ds_min_u32 (1 v_lshl_or_b32 + 1 LDS atomic per 16 distances; the LDS instruction does not
+//     hold the VALU).  The running minimum never rises, so the word ends up holding (best distance, FIRST group in
+//     which the running minimum reached it);
+//   * after the scan, the lane re-reads just that group's 16 rows (per-lane global loads, L2-resident: the frame
+//     was streamed a moment ago) and takes min(dist << 22 | row): the first row of the first group with the best
+//     distance = the first minimum.  16 of ~2000 rows = 0.8 % extra distances.
+//
+// The words are lane-private (index j * THREADS + tid): LDS serves as 8 extra registers with a free min-ALU, no
+// barrier is involved.
 // ---------------------------------------------------------------------------------------------------
+constexpr int ARGMIN_GROUP = 16;      // train rows per (dist, group) key; a multiple of the 4 rows of one loop trip
+
 template <int THREADS, int QPT, bool ARGMIN, bool WRITE_KEYS>
 __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
     // ARGMIN = false with WRITE_KEYS = true writes the best DISTANCE per query row (split mode, see k_finalize_pairs)
-    constexpr int DSHIFT = ARGMIN ? KEY_SHIFT : 0;      // best[j] >> DSHIFT is the best distance
+    constexpr int DSHIFT = ARGMIN ? KEY_SHIFT : 0;      // best[j] >> DSHIFT is the best distance (epilogue)
     __shared__ uint32_t red_min[2];
     __shared__ uint32_t red_sum[2];
+    __shared__ uint32_t red_idx[2];
+    __shared__ uint32_t lane_key[ARGMIN ? THREADS * QPT : 1];
 
     const int tid = threadIdx.x;
-    if (tid == 0) { red_min[0] = red_min[1] = 0xFFFFFFFFu; red_sum[0] = red_sum[1] = 0u; }
+    if (tid == 0) { red_min[0] = red_min[1] = 0xFFFFFFFFu; red_sum[0] = red_sum[1] = 0u; red_idx[0] = red_idx[1] = 0u; }
     __syncthreads();
 
     WorkItem it;
@@ -151,6 +200,15 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
         uint32_t best[QPT];
 #pragma unroll
         for (int j = 0; j < QPT; ++j) best[j] = 0xFFFFFFFFu;
+        if (ARGMIN) {
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) lane_key[j * THREADS + tid] = 0xFFFFFFFFu;
+        }
+        // (dist, group) fold of this lane's running minima into its private LDS words
+        auto fold_group = [&](uint32_t g) {
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) atomicMin(&lane_key[j * THREADS + tid], (best[j] << KEY_SHIFT) | g);
+        };
 
         // Train rows are stored padded to a multiple of 4 rows with copies of the LAST real row: a copy has the
         // same distance and a higher index than the row it copies, so it can never win the (dist, idx) minimum.
@@ -166,21 +224,46 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
                 for (int k = 0; k < 16; ++k) B[k] = T[(t + 2) * 8 + k];
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the VALU block it overlaps
 #pragma unroll
-                for (int j = 0; j < QPT; ++j) {
-                    if (ARGMIN) fold2(best[j], q[j], A, (uint32_t)t, (uint32_t)(t + 1)); else fold2_min(best[j], q[j], A);
-                }
+                for (int j = 0; j < QPT; ++j) fold2_min(best[j], q[j], A);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): B landed while A was being consumed
 #pragma unroll
                 for (int k = 0; k < 16; ++k) A[k] = T[(t + 4) * 8 + k];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < QPT; ++j) {
-                    if (ARGMIN) fold2(best[j], q[j], B, (uint32_t)(t + 2), (uint32_t)(t + 3)); else fold2_min(best[j], q[j], B);
-                }
+                for (int j = 0; j < QPT; ++j) fold2_min(best[j], q[j], B);
                 __builtin_amdgcn_sched_barrier(0);
+                if (ARGMIN && (t & (ARGMIN_GROUP - 4)) == (ARGMIN_GROUP - 4)) fold_group((uint32_t)t / ARGMIN_GROUP);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // A (rows t+4, t+5) landed while B was being consumed
             }
+            if (ARGMIN) {
+                // the last, possibly partial group (a repeat of an already folded group changes nothing) ...
+                fold_group((uint32_t)(nt - 1) / ARGMIN_GROUP);
+                // ... then the re-scan of each query row's winning group for the first row that attains the minimum
+                const uint32_t* Tg = a.db_rows + (size_t)slot * a.db_stride_words;      // wave-uniform frame base
+                const uint32_t last_off = (uint32_t)(nt - 1) * 32u;
+#pragma unroll
+                for (int j = 0; j < QPT; ++j) {
+                    // one query row at a time, the group's rows one after the other: the re-scan is < 1 % of the work
+                    // and must not cost the main loop a register (64 of its 80 hold the query rows)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!valid(j)) continue;
+                    const uint32_t row0 = (lane_key[j * THREADS + tid] & KEY_IDX_MASK) * ARGMIN_GROUP;
+                    uint32_t kmin = 0xFFFFFFFFu;
+#pragma unroll 1
+                    for (uint32_t r = 0; r < (uint32_t)ARGMIN_GROUP; ++r) {
+                        // rows past the frame's end re-read the last row under a HIGHER index: they cannot win
+                        const uint32_t d = rescan_distance(q[j], Tg, min((row0 + r) * 32u, last_off));
+                        kmin = min(kmin, (d << KEY_SHIFT) | (row0 + r));
+                    }
+                    lane_key[j * THREADS + tid] = kmin;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ARGMIN) {        // from here on best[j] is the packed key dist << 22 | first train row (0xFFFFFFFF: no train rows)
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) best[j] = lane_key[j * THREADS + tid];
         }
 
         // ---- pair epilogue: min-of-mins, ratio filter count, one score record
@@ -203,13 +286,18 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
         atomicMin(&red_min[par], dmin);
         __syncthreads();
         dmin = red_min[par];
-        if (tid == 0) { red_min[par ^ 1] = 0xFFFFFFFFu; red_sum[par ^ 1] = 0u; }   // next pair's words (idle until B)
+        if (tid == 0) { red_min[par ^ 1] = 0xFFFFFFFFu; red_sum[par ^ 1] = 0u; red_idx[par ^ 1] = 0u; }   // next pair's words (idle until B)
         uint32_t thr = (uint32_t)a.ratio * dmin;
         thr = max(thr, (uint32_t)a.dist_floor);
-        uint32_t cnt = 0;
+        uint32_t cnt = 0, isum = 0;
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) cnt += (valid(j) && (best[j] >> DSHIFT) <= thr) ? 1u : 0u;
+        for (int j = 0; j < QPT; ++j) {
+            const bool good = valid(j) && (best[j] >> DSHIFT) <= thr;
+            cnt += good ? 1u : 0u;
+            if (ARGMIN) isum += good ? (best[j] & KEY_IDX_MASK) : 0u;
+        }
         atomicAdd(&red_sum[par], cnt);
+        if (ARGMIN && a.idx_sums) atomicAdd(&red_idx[par], isum);
         __syncthreads();
         cnt = red_sum[par];
         if (tid == 0) {
@@ -218,6 +306,7 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
             rec.x = empty ? 0u : cnt;
             rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
             reinterpret_cast<uint2*>(a.scores)[out] = rec;
+            if (ARGMIN && a.idx_sums) a.idx_sums[out] = empty ? 0u : red_idx[par];
         }
     }
 }
@@ -451,15 +540,18 @@ hipError_t launch_score_split(const ScoreArgs& a, uint32_t n_items, int qpt, hip
 }
 
 // ---------------------------------------------------------------------------------------------------
-// On-device loop test (README.md:123-126) over the score array: one thread per pair, candidates compacted with an
-// atomic counter.  The division is IEEE double (no fast-math), so the verdict is bit-identical to the host's.
+// On-device loop test (README.md:123-126) over the score array, candidates compacted IN PAIR ORDER — (query frame
+// ascending, stored frame ascending) = (current id, matched id) ascending, the order detectLoops reports — so the host
+// never sorts: k_loop_count (verdict per pair, candidates per 256-pair block), k_block_scan (exclusive prefix of the
+// block counts, one workgroup), k_loop_emit (verdict again, rank inside the block by wave ballots, write).
+// The division is IEEE double (no fast-math), so the verdict is bit-identical to the host's lcm_loop_test.
+// HBM-bound: 2 x 8 bytes read per pair + 24 bytes written per candidate.
 // ---------------------------------------------------------------------------------------------------
 struct CandidateRec { int32_t cur, matched, num; int32_t pad; double sim; };
 static_assert(sizeof(CandidateRec) == 24, "lcm_loop_candidate layout");
 
-__global__ __launch_bounds__(256) void k_loop_test(LoopTestArgs a) {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= a.n_pairs) return;
+__device__ __forceinline__ bool loop_verdict(const LoopTestArgs& a, uint32_t p, CandidateRec& r) {
+    if (p >= a.n_pairs) return false;
     // query frame of pair p: last c with offsets[c] <= p
     uint32_t lo = 0, hi = a.n_q;
     while (hi - lo > 1) {
@@ -470,20 +562,65 @@ __global__ __launch_bounds__(256) void k_loop_test(LoopTestArgs a) {
     const uint2 rec = reinterpret_cast<const uint2*>(a.scores)[p];
     const uint32_t good = rec.x;
     const int den = min(a.q_kp[c], a.db_kp[slot]);
-    if (den <= 0 || (int64_t)good < (int64_t)a.min_matches) return;
+    if (den <= 0 || (int64_t)good < (int64_t)a.min_matches) return false;
     const double sim = (double)good / (double)den;
-    if (!(sim > a.sim_threshold)) return;
-    const uint32_t k = atomicAdd(a.counter, 1u);
-    if (k < a.cap) {
-        CandidateRec r;
-        r.cur = a.q_ids[c]; r.matched = a.db_ids[slot]; r.num = (int32_t)good; r.pad = 0; r.sim = sim;
-        reinterpret_cast<CandidateRec*>(a.out)[k] = r;
+    if (!(sim > a.sim_threshold)) return false;
+    r.cur = a.q_ids[c]; r.matched = a.db_ids[slot]; r.num = (int32_t)good; r.pad = 0; r.sim = sim;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_loop_count(LoopTestArgs a) {
+    CandidateRec r;
+    const bool pass = loop_verdict(a, blockIdx.x * 256u + threadIdx.x, r);
+    const int n = __syncthreads_count(pass ? 1 : 0);
+    if (threadIdx.x == 0) a.block_counts[blockIdx.x] = (uint32_t)n;
+}
+
+// counts[0..n) -> exclusive prefix sums in place; *total = sum.  One workgroup of 1024 threads, chunk by chunk.
+__global__ __launch_bounds__(1024) void k_block_scan(uint32_t* counts, uint32_t n, uint32_t* total) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < n ? counts[i] : 0u;
+        uint32_t x = v;                                   // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wave_sum[wave] = x;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_sum[w];
+        if (i < n) counts[i] = before + x - v;
+        __syncthreads();
+        if (tid == 1023) carry = before + x;
+        __syncthreads();
     }
+    if (tid == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_loop_emit(LoopTestArgs a) {
+    __shared__ uint32_t wave_n[4];
+    CandidateRec r;
+    const bool pass = loop_verdict(a, blockIdx.x * 256u + threadIdx.x, r);
+    const uint64_t m = __ballot(pass);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_n[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (!pass) return;
+    uint32_t k = a.block_counts[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) k += wave_n[w];
+    if (k < a.cap) reinterpret_cast<CandidateRec*>(a.out)[k] = r;
 }
 
 hipError_t launch_loop_test(const LoopTestArgs& a, hipStream_t st) {
     if (a.n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_loop_test, dim3((a.n_pairs + 255) / 256), dim3(256), 0, st, a);
+    const uint32_t n_blocks = (a.n_pairs + 255) / 256;
+    hipLaunchKernelGGL(k_loop_count, dim3(n_blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, a.block_counts, n_blocks, a.counter);
+    hipLaunchKernelGGL(k_loop_emit, dim3(n_blocks), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

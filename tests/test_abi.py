@@ -107,6 +107,7 @@ def test_null_handle_calls_fail_cleanly(pkg):
     assert lib.lcm_query_scores(None, buf, 1, 0, buf, buf, C.byref(n)) == -1
     assert lib.lcm_detect_loops(None, 0, buf, 1, 1, buf, 1, C.byref(n)) == -1
     assert lib.lcm_all_vs_all(None, None, None, None, 0, 0, None, 0, C.byref(z), None) == -1
+    assert lib.lcm_all_vs_all_argmin(None, None, None, None, 0, 0, None, 0, None, C.byref(z), None) == -1
     assert lib.lcm_all_vs_all_loops(None, None, None, None, None, 0, 0, None, 0, C.byref(z), C.byref(z)) == -1
     assert lib.lcm_last_launch_info(None, C.byref(info)) == -1
     assert lib.lcm_set_kernel_variant(None, 0) == -1

@@ -40,7 +40,9 @@ def test_cfg4_fullsize_fused_filter_and_loop_test(pkg, oracle):
         fb = fs.stride_rows * 32
         for f in range(fs.n_frames):
             m.append_device(int(fs.ids[f]), d_rows + f * fb, int(fs.counts[f]))
-        cands, n_pairs = m.all_vs_all_loops(cap=1 << 22)
+        # nearly every pair is a "loop" by the README's rule on this data (unrelated frames: best distances 88..107,
+        # so 2 x min keeps all 2000 matches): the candidate buffer must hold one record per pair
+        cands, n_pairs = m.all_vs_all_loops(out=np.zeros(12352935, pkg.capi.CANDIDATE_DTYPE))
         info = m.launch_info()
         assert n_pairs == 12352935 == pkg.synth.n_pairs_all_vs_all(5000, GAP)
         assert info.distances == n_pairs * 2000 * 2000 and info.aux_kernel_ms > 0
@@ -57,7 +59,7 @@ def test_cfg4_fullsize_fused_filter_and_loop_test(pkg, oracle):
     den = np.minimum(fs.counts[c_of], fs.counts[t_of]).astype(np.float64)
     sim = good.astype(np.float64) / den
     keep = np.nonzero((sim > 0.15) & (good >= 50))[0]
-    assert len(keep) > 500                                        # every frame revisits its place 1250 frames later
+    assert len(keep) > 500 and (~((sim > 0.15) & (good >= 50))).sum() > 500     # both verdicts occur
     assert len(cands) == len(keep)
     np.testing.assert_array_equal(cands["current_frame_id"], fs.ids[c_of[keep]])
     np.testing.assert_array_equal(cands["matched_frame_id"], fs.ids[t_of[keep]])

@@ -124,15 +124,27 @@ def test_cfg2_full_database_sampled_vs_oracle_and_sharded(matcher, oracle, pkg):
 
         matcher.set_kernel_variant(1)
         keyed, _ = run(range(1000), False)
+        argmin_ms = matcher.launch_info().kernel_ms
         matcher.set_kernel_variant(0)
         np.testing.assert_array_equal(keyed, full)
+        # the argmin kernel may cost at most a few per cent over the distance-only one (measured: see DESIGN.md §5)
+        assert argmin_ms < 1.10 * info.kernel_ms, (argmin_ms, info.kernel_ms)
+        # ... and its indices, through the per-pair checksum of lcm_all_vs_all_argmin, against the oracle on a sample
+        d_sc, d_su = matcher.dev_alloc(470935 * 8), matcher.dev_alloc(470935 * 4)
+        assert matcher.all_vs_all_argmin(d_sc, 470935, d_su) == 470935
+        sc2, sums = np.zeros(470935, pkg.capi.SCORE_DTYPE), np.zeros(470935, np.uint32)
+        matcher.sync()
+        matcher.dev_download(d_sc, sc2); matcher.dev_download(d_su, sums)
+        matcher.dev_free(d_sc); matcher.dev_free(d_su)
+        np.testing.assert_array_equal(sc2, full)
 
         rng = np.random.default_rng(7)
         qs = rng.integers(gap, 1000, 200)
         ts = np.array([rng.integers(0, q - gap + 1) for q in qs])
         p = oracle.default_params(min_gap=gap)
-        cpu, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, qs, ts, p, n_threads=8)
+        cpu, cpu_sums = oracle.fast_score_pairs_idx(fs.rows, fs.counts, qs, ts, p, n_threads=8)
         np.testing.assert_array_equal(full[offs[qs].astype(np.int64) + ts], cpu)
+        np.testing.assert_array_equal(sums[offs[qs].astype(np.int64) + ts], cpu_sums)
         for q, t in zip(qs[:3], ts[:3]):
             assert full[int(offs[q]) + int(t)] == oracle.pair_score(fs.frame(q), fs.frame(t), p)
 

@@ -397,3 +397,51 @@ def test_create_use_destroy_cycles(pkg):
         np.testing.assert_array_equal(s, ref[0])
         np.testing.assert_array_equal(idx, ref[1])
         a.close()
+
+
+def gpu_all_vs_all_argmin(m, pkg):
+    n, offs = m.all_vs_all_plan()
+    d_scores = m.dev_alloc(max(n, 1) * 8)
+    d_sums = m.dev_alloc(max(n, 1) * 4)
+    try:
+        assert m.all_vs_all_argmin(d_scores, n, d_sums) == n
+        scores = np.zeros(max(n, 1), pkg.capi.SCORE_DTYPE)
+        sums = np.zeros(max(n, 1), np.uint32)
+        m.sync()
+        m.dev_download(d_scores, scores)
+        m.dev_download(d_sums, sums)
+    finally:
+        m.dev_free(d_scores); m.dev_free(d_sums)
+    return scores[:n], sums[:n], offs
+
+
+@pytest.mark.parametrize("n_frames,max_desc,gap,seed", [(26, 700, 3, 41), (12, 2000, 2, 8), (40, 130, 1, 17), (18, 1100, 2, 5)])
+def test_argmin_kernel_index_checksum(matcher, oracle, pkg, n_frames, max_desc, gap, seed):
+    """lcm_all_vs_all_argmin: the first-minimum TRAIN INDEX of every query row is found by the bulk kernel itself
+    (16-row group keys + re-scan of the winning group); the per-pair checksum of the good matches' indices must equal
+    the oracle's.  Heavy ties: duplicated rows inside a frame, across frames, across 16-row group boundaries."""
+    fs = pkg.synth.make_frames(n_frames, max_desc, seed=seed, ragged=True, dup_frac=0.5)
+    fs.counts[4] = 0
+    fs.counts[9] = 1
+    n7 = int(fs.counts[7])
+    fs.rows[7, : n7 // 2] = fs.rows[3, : n7 // 2]                     # frame 7 duplicates half of frame 3 ...
+    fs.rows[3, 16:48] = fs.rows[3, 0:32]                              # ... which repeats its own rows 16 further on
+    fs.rows[6, 15] = fs.rows[6, 16] = fs.rows[6, 31] = fs.rows[6, 32]  # ties straddling group boundaries
+    matcher.set_params(min_gap=gap)
+    try:
+        fill(matcher, fs)
+        scores, sums, offs = gpu_all_vs_all_argmin(matcher, pkg)
+        pq, pt = [], []
+        for c in range(n_frames):
+            for t in range(n_frames):
+                if fs.ids[c] - fs.ids[t] >= gap:
+                    pq.append(c); pt.append(t)
+        want, wsums = oracle.fast_score_pairs_idx(fs.rows, fs.counts, pq, pt, oracle.default_params(min_gap=gap), n_threads=8)
+        np.testing.assert_array_equal(scores, want)
+        np.testing.assert_array_equal(sums, wsums)
+        rng = np.random.default_rng(seed)
+        for k in rng.choice(len(pq), 6, replace=False):               # and straight from the scalar oracle's match list
+            assert int(sums[k]) == oracle.index_sum(fs.frame(pq[k]), fs.frame(pt[k]), oracle.default_params(min_gap=gap))
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()

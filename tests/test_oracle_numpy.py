@@ -60,3 +60,21 @@ def test_all_vs_all_shards_partition_the_pairs(oracle, pkg):
     merged, moffs = pkg.sharding.merge_shard_scores(shards, fs.ids, 3)
     np.testing.assert_array_equal(merged, full)
     np.testing.assert_array_equal(moffs, offs.astype(np.int64))
+
+
+def test_fast_path_index_checksum_equals_scalar_match_features(oracle, pkg):
+    """orc_fast_score_pairs_idx's per-pair checksum (sum of the good matches' trainIdx mod 2^32) == the same sum formed
+    from the scalar oracle's matchFeatures list; ties, ragged sizes, an empty frame and min_dist == 0 included."""
+    fs = pkg.synth.make_frames(14, 180, seed=99, ragged=True, dup_frac=0.5)
+    fs.counts[5] = 0
+    fs.rows[7, :40] = fs.rows[3, :40]                       # exact duplicates across frames: min_dist == 0, many ties
+    fs.rows[7, 40:80] = fs.rows[3, :40]
+    p = oracle.default_params(min_gap=1)
+    pq = [c for c in range(14) for t in range(14) if c != t]
+    pt = [t for c in range(14) for t in range(14) if c != t]
+    scores, sums = oracle.fast_score_pairs_idx(fs.rows, fs.counts, pq, pt, p, n_threads=3)
+    plain, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, pq, pt, p, n_threads=3)
+    np.testing.assert_array_equal(scores, plain)
+    for k, (c, t) in enumerate(zip(pq, pt)):
+        assert int(sums[k]) == oracle.index_sum(fs.frame(c), fs.frame(t), p), (c, t)
+    assert len(set(sums.tolist())) > 50
