@@ -216,6 +216,56 @@ LCM_API int  lcm_last_bulk_scores(const lcm_handle* h, const void** d_scores, si
  * queries and wavefront shuffle reductions, distances only / (dist, idx) keys. */
 LCM_API int  lcm_set_kernel_variant(lcm_handle* h, int variant);
 
+/* ---- multi-GPU: one process, W devices, stored frames sharded cyclically by arrival position ------------------- */
+/* What a LoopClosingSystem (include/loop_closing.hpp:29-31) holds instead of one matcher when it is given more than
+ * one MI355X: one lcm_handle + one host thread per device, an RCCL communicator (ncclCommInitAll) over them.  Stored
+ * frame number p (arrival order) lives on device p mod W.  lcm_group_all_vs_all all-gathers the shard arenas over
+ * xGMI so that every device sees every frame as a query, scores on all devices at once, gathers the 8-byte records to
+ * the first device (grouped ncclSend / ncclRecv), un-permutes them on that device and returns the SAME array, in
+ * the same order, that a single lcm_handle holding all frames would have produced with lcm_all_vs_all. */
+typedef struct lcm_group lcm_group;
+typedef struct lcm_group_info {
+    int32_t  n_devices;
+    uint64_t pairs, distances, algo_bytes;   /* summed over the shards */
+    double   kernel_ms_max;                  /* slowest shard's scoring kernel(s) */
+    double   gather_merge_ms;                /* first device: its kernel's end -> records gathered (RCCL) and merged */
+    double   download_ms;                    /* merged array -> host */
+    uint64_t gathered_query_bytes;           /* per device: bytes received by the all-gather of the shard arenas */
+    uint64_t gathered_score_bytes;           /* bytes of score records that crossed xGMI to the first device */
+} lcm_group_info;
+/* device_ids == NULL: devices 0 .. n_devices-1.  n_devices <= 8. */
+LCM_API int  lcm_group_create(const lcm_params* params, int n_devices, const int* device_ids, lcm_group** out);
+LCM_API void lcm_group_destroy(lcm_group* g);
+LCM_API int  lcm_group_size(const lcm_group* g);                    /* W */
+LCM_API int  lcm_group_db_size(const lcm_group* g);                 /* frames over all shards */
+LCM_API int  lcm_group_handle(lcm_group* g, int rank, lcm_handle** out);   /* the shard's own matcher (borrowed) */
+LCM_API int  lcm_group_set_params(lcm_group* g, const lcm_params* params);
+LCM_API int  lcm_group_reserve(lcm_group* g, int n_frames, int max_desc);
+LCM_API int  lcm_group_append(lcm_group* g, int frame_id, const uint8_t* desc, int n, int n_keypoints);
+LCM_API int  lcm_group_clear(lcm_group* g);
+/* out_scores (host) receives *n_pairs records in (query ascending, stored ascending) order; pair_offsets (host,
+ * optional, db_size + 1 entries); out_scores == NULL sizes only. */
+LCM_API int  lcm_group_all_vs_all(lcm_group* g, lcm_score* out_scores, size_t cap, size_t* n_pairs, size_t* pair_offsets);
+LCM_API int  lcm_group_last_info(const lcm_group* g, lcm_group_info* info);
+/* lcm_query_scores / lcm_detect_loops over all shards (query uploaded to every device; per-shard records interleaved
+ * on the host: a few KB per query). */
+LCM_API int  lcm_group_query_scores(lcm_group* g, const uint8_t* query, int nq, int query_frame_id,
+                                    lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out);
+LCM_API int  lcm_group_detect_loops(lcm_group* g, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
+                                    lcm_loop_candidate* out, int cap, int* n_out);
+/* Host-only (no device needed): merge W per-shard score arrays — shard r in (query ascending, owned stored ascending)
+ * order, as a process-per-GPU deployment gathers them (bench.py, torch.distributed) — into the single-device order.
+ * ids: all n_frames frame ids, ascending.  out == NULL sizes only (*n_out, offsets[n_frames + 1] optional). */
+LCM_API int  lcm_merge_shard_scores(const lcm_score* const* shard_scores, const size_t* shard_counts, int world,
+                                    const int32_t* ids, int n_frames, int min_gap,
+                                    lcm_score* out, size_t cap, size_t* n_out, size_t* offsets);
+
+/* The same merge on the device (what lcm_group_all_vs_all runs on its first device): d_gathered holds the W shard
+ * arrays back to back; d_merged receives the single-device order.  world <= 8. */
+LCM_API int  lcm_merge_shard_scores_device(lcm_handle* h, const void* d_gathered, const size_t* shard_counts, int world,
+                                           const int32_t* ids, int n_frames, int min_gap,
+                                           void* d_merged, size_t cap, size_t* n_out);
+
 /* Measurement knobs (defaults are the measured optima; results never depend on them):
  *   LCM_TUNE_ITEM_SLOTS   stored frames per work item of the bulk search, 1..64; 0 = automatic
  *   LCM_TUNE_ONLINE_SPLIT query rows per lane of the online split mode: 1, 2, 4; 0 = never split; -1 = automatic */

@@ -6,6 +6,6 @@ is the ctypes plumbing used by tests, bench.py and __graft_entry__; the director
 loaded by path (see `load_package` in __graft_entry__.py) under the module name `slam_loop_closing_amd`.
 """
 from . import capi, synth, sharding  # noqa: F401
-from .capi import Matcher, LoopClosingSystem, LcmError, default_params, load_library  # noqa: F401
+from .capi import Matcher, Group, LoopClosingSystem, LcmError, default_params, load_library  # noqa: F401
 
-__all__ = ["capi", "synth", "sharding", "Matcher", "LoopClosingSystem", "LcmError", "default_params", "load_library"]
+__all__ = ["capi", "synth", "sharding", "Matcher", "Group", "LoopClosingSystem", "LcmError", "default_params", "load_library"]

@@ -49,6 +49,12 @@ class LaunchInfo(C.Structure):
                 ("aux_kernel_ms", C.c_double)]
 
 
+class GroupInfo(C.Structure):
+    _fields_ = [("n_devices", C.c_int32), ("pairs", C.c_uint64), ("distances", C.c_uint64), ("algo_bytes", C.c_uint64),
+                ("kernel_ms_max", C.c_double), ("gather_merge_ms", C.c_double), ("download_ms", C.c_double),
+                ("gathered_query_bytes", C.c_uint64), ("gathered_score_bytes", C.c_uint64)]
+
+
 SCORE_DTYPE = np.dtype([("good_count", "<u4"), ("min_dist", "<u2"), ("n_train", "<u2")])
 DMATCH_DTYPE = np.dtype([("query_idx", "<i4"), ("train_idx", "<i4"), ("img_idx", "<i4"), ("distance", "<f4")])
 CANDIDATE_DTYPE = np.dtype([("current_frame_id", "<i4"), ("matched_frame_id", "<i4"), ("num_matches", "<i4"),
@@ -101,6 +107,23 @@ _SIGNATURES = {
     "lcm_last_bulk_scores": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "lcm_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
     "lcm_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "lcm_group_create": (C.c_int, [C.POINTER(Params), C.c_int, _i32p, C.POINTER(_vp)]),
+    "lcm_group_destroy": (None, [_vp]),
+    "lcm_group_size": (C.c_int, [_vp]),
+    "lcm_group_db_size": (C.c_int, [_vp]),
+    "lcm_group_handle": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "lcm_group_set_params": (C.c_int, [_vp, C.POINTER(Params)]),
+    "lcm_group_reserve": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "lcm_group_append": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
+    "lcm_group_clear": (C.c_int, [_vp]),
+    "lcm_group_all_vs_all": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
+    "lcm_group_last_info": (C.c_int, [_vp, C.POINTER(GroupInfo)]),
+    "lcm_group_query_scores": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _i32p]),
+    "lcm_group_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
+    "lcm_merge_shard_scores": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
+                                          C.POINTER(C.c_size_t), _vp]),
+    "lcm_merge_shard_scores_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
+                                                 C.POINTER(C.c_size_t)]),
     "lcm_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "lcm_dev_free": (C.c_int, [_vp, _vp]),
     "lcm_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -379,6 +402,15 @@ class Matcher:
             self.dev_download(p.value, out)
         return out
 
+    def merge_shards_device(self, d_gathered: int, shard_counts: Sequence[int], ids, min_gap: int, d_merged: int, cap: int) -> int:
+        world = len(shard_counts)
+        counts = (C.c_size_t * world)(*[int(c) for c in shard_counts])
+        ids = np.ascontiguousarray(ids, np.int32)
+        n = C.c_size_t(0)
+        _check(self._lib.lcm_merge_shard_scores_device(self._h, _vp(d_gathered), counts, world, _ptr(ids), len(ids), min_gap,
+                                                       _vp(d_merged), cap, C.byref(n)))
+        return n.value
+
     def launch_info(self) -> LaunchInfo:
         info = LaunchInfo()
         _check(self._lib.lcm_last_launch_info(self._h, C.byref(info)))
@@ -400,6 +432,107 @@ class Matcher:
     def dev_download(self, d_ptr: int, out: np.ndarray):
         assert out.flags["C_CONTIGUOUS"]
         _check(self._lib.lcm_dev_download(self._h, out.ctypes.data_as(_vp), _vp(d_ptr), out.nbytes))
+
+
+def merge_shard_scores_host(shard_scores: Sequence[np.ndarray], ids, min_gap: int) -> Tuple[np.ndarray, np.ndarray]:
+    """lcm_merge_shard_scores (host-only C function): W per-shard arrays -> (merged, offsets[n_frames + 1])."""
+    lib = load_library()
+    world = len(shard_scores)
+    arrs = [np.ascontiguousarray(a, SCORE_DTYPE) for a in shard_scores]
+    ptrs = (_vp * world)(*[a.ctypes.data if a.size else None for a in arrs])
+    counts = (C.c_size_t * world)(*[len(a) for a in arrs])
+    ids = np.ascontiguousarray(ids, np.int32)
+    n = C.c_size_t(0)
+    offs = np.zeros(len(ids) + 1, np.uintp)
+    _check(lib.lcm_merge_shard_scores(ptrs, counts, world, _ptr(ids), len(ids), min_gap, None, 0, C.byref(n),
+                                      offs.ctypes.data_as(_vp)))
+    out = np.zeros(max(n.value, 1), SCORE_DTYPE)
+    _check(lib.lcm_merge_shard_scores(ptrs, counts, world, _ptr(ids), len(ids), min_gap, out.ctypes.data_as(_vp),
+                                      len(out), C.byref(n), None))
+    return out[: n.value], offs
+
+
+class Group:
+    """lcm_group: one process, W devices, stored frames sharded cyclically by arrival position, RCCL inside."""
+
+    def __init__(self, params: Optional[Params] = None, n_devices: int = 1, device_ids: Optional[Sequence[int]] = None):
+        self._lib = load_library()
+        self._g = _vp()
+        p = params if params is not None else default_params()
+        ids = None if device_ids is None else np.ascontiguousarray(device_ids, np.int32)
+        _check(self._lib.lcm_group_create(C.byref(p), n_devices, None if ids is None else ids.ctypes.data_as(_i32p),
+                                          C.byref(self._g)))
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.lcm_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __len__(self):
+        return self._lib.lcm_group_db_size(self._g)
+
+    @property
+    def world(self) -> int:
+        return self._lib.lcm_group_size(self._g)
+
+    def set_params(self, p: Params):
+        _check(self._lib.lcm_group_set_params(self._g, C.byref(p)))
+
+    def reserve(self, n_frames: int, max_desc: int):
+        _check(self._lib.lcm_group_reserve(self._g, n_frames, max_desc))
+
+    def append(self, frame_id: int, desc, n_keypoints: int = -1):
+        d = _rows(desc)
+        _check(self._lib.lcm_group_append(self._g, frame_id, _ptr(d), d.shape[0], n_keypoints))
+
+    def clear(self):
+        _check(self._lib.lcm_group_clear(self._g))
+
+    def all_vs_all(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(merged scores in (query asc, stored asc) order, offsets[len + 1])."""
+        n = C.c_size_t(0)
+        offs = np.zeros(len(self) + 1, np.uintp)
+        _check(self._lib.lcm_group_all_vs_all(self._g, None, 0, C.byref(n), offs.ctypes.data_as(_vp)))
+        out = np.zeros(max(n.value, 1), SCORE_DTYPE)
+        _check(self._lib.lcm_group_all_vs_all(self._g, out.ctypes.data_as(_vp), len(out), C.byref(n), None))
+        return out[: n.value], offs
+
+    def info(self) -> GroupInfo:
+        gi = GroupInfo()
+        _check(self._lib.lcm_group_last_info(self._g, C.byref(gi)))
+        return gi
+
+    def query_scores(self, query, query_frame_id: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _rows(query)
+        cap = max(len(self), 1)
+        scores = np.zeros(cap, SCORE_DTYPE)
+        ids = np.zeros(cap, np.int32)
+        n = C.c_int32(0)
+        _check(self._lib.lcm_group_query_scores(self._g, _ptr(q), q.shape[0], query_frame_id, scores.ctypes.data_as(_vp),
+                                                ids.ctypes.data_as(_vp), cap, C.byref(n)))
+        return scores[: n.value], ids[: n.value]
+
+    def detect_loops(self, current_frame_id: int, query, n_keypoints: int = -1) -> np.ndarray:
+        q = _rows(query)
+        cap = max(len(self), 1)
+        out = np.zeros(cap, CANDIDATE_DTYPE)
+        n = C.c_int32(0)
+        qp = q.ctypes.data_as(_vp) if q.shape[0] else np.zeros((1, DESC_BYTES), np.uint8).ctypes.data_as(_vp)
+        _check(self._lib.lcm_group_detect_loops(self._g, current_frame_id, qp, q.shape[0], n_keypoints,
+                                                out.ctypes.data_as(_vp), cap, C.byref(n)))
+        return out[: n.value]
 
 
 # ---------------------------------------------------------------------------------------------------------

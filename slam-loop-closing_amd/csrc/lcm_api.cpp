@@ -6,175 +6,26 @@
 // pair-scoring kernel, and the host-side IEEE-double loop test (README.md:123-126).
 //
 // There is no CPU compute path in this file: every distance is computed by the kernels in lcm_kernels.hip.
-#include "../../include/lcm.h"
+#include "lcm_internal.h"
 
-#include <hip/hip_runtime.h>
-#include <sys/stat.h>
-
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "lcm_kernels.h"
-
-namespace {
-
-thread_local std::string g_err;
-
+namespace lcm {
+std::string& last_error() { static thread_local std::string e; return e; }
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    g_err = buf;
+    last_error() = buf;
     return code;
 }
-
-// Nothing may throw across the C boundary (include/lcm.h): every entry point that touches a std container runs inside
-// this guard, which turns std::bad_alloc into LCM_ERR_OOM and anything else into LCM_ERR_HIP + message.
-template <typename F>
-int guarded(F&& f) noexcept {
-    try { return f(); }
-    catch (const std::bad_alloc&) { return fail(LCM_ERR_OOM, "host allocation failed (std::bad_alloc)"); }
-    catch (const std::exception& e) { return fail(LCM_ERR_HIP, "unexpected C++ exception: %s", e.what()); }
-    catch (...) { return fail(LCM_ERR_HIP, "unexpected C++ exception"); }
-}
-
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(e_ == hipErrorOutOfMemory ? LCM_ERR_OOM : LCM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
-                        hipGetErrorString(e_), __FILE__, __LINE__);                                \
-    } while (0)
-
-constexpr int ROW_PAD = 4;            // stored rows are padded to a multiple of 4 with copies of the last row
-constexpr size_t ARENA_SLACK = 512;   // the kernel prefetches up to 4 rows past a frame's padded end
-constexpr int DEFAULT_MAX_DESC = 2000;  // ORB nfeatures of the reference (README.md:114)
-constexpr int STAGE_BUFS = 2;
-
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-struct FrameMeta {
-    int32_t id;
-    int32_t n;       // descriptor rows
-    int32_t n_kp;    // keypoints (similarity denominator)
-};
-
-constexpr int QUERY_SLOTS = 4;    // online queries that may be in flight at once (lcm_query_submit / _collect)
-
-struct QuerySlot {                // everything one in-flight online query owns
-    bool busy = false;
-    int n_elig = 0, nq = 0, query_id = 0;
-    uint64_t db_generation = 0;   // h->db_generation at submit: a clear / load in between invalidates the ticket
-    uint8_t* h_query = nullptr;   size_t h_query_bytes = 0;    // pinned staging of the query rows
-    lcm_score* h_scores = nullptr; size_t h_scores_n = 0;      // pinned landing zone of the score records
-    uint8_t* d_query = nullptr;   size_t d_query_bytes = 0;
-    lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
-    uint32_t* d_dist = nullptr;   size_t d_dist_n = 0;         // split mode: best distance per (pair, row)
-    hipEvent_t done = nullptr;
-};
-
-struct Plan {            // cached work list of one bulk call shape
-    uint64_t key = 0;    // hash of what it was built from
-    std::vector<lcm::WorkItem> items;
-    std::vector<size_t> offsets;    // per query frame, start of its run of pairs (n_q + 1)
-    lcm::WorkItem* d_items = nullptr;
-    size_t d_items_cap = 0;
-    size_t n_pairs = 0;
-    uint64_t distances = 0, algo_bytes = 0;
-    int max_q_rows = 0;
-};
-
-}  // namespace
-
-namespace lcm {
-void set_last_error(const char* msg) { g_err = msg ? msg : ""; }   // for the host-class shim (lcs_host.cpp)
-}
-
-struct lcm_handle {
-    lcm_params params;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t db_ready = nullptr;     // last append landed (recorded on copy_stream)
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    hipEvent_t ev_aux_start = nullptr, ev_aux_stop = nullptr;   // the follow-up kernel of a call (k_loop_test, ...)
-    bool aux_pending = false;
-    int variant = 0;
-    int tune_item_slots = 0;           // 0 = automatic (pick_chunk)
-    int tune_online_split = -1;        // -1 = automatic (enqueue_query)
-
-    // database arena
-    uint8_t* d_rows = nullptr;
-    int32_t* d_counts = nullptr;
-    int cap_frames = 0;
-    int stride_rows = 0;               // rows per frame slot (multiple of ROW_PAD)
-    std::vector<FrameMeta> frames;
-    bool pending_copy = false;
-
-    // pinned staging ring for streaming appends
-    uint8_t* h_stage[STAGE_BUFS] = {nullptr, nullptr};
-    size_t h_stage_bytes = 0;
-    hipEvent_t stage_done[STAGE_BUFS] = {nullptr, nullptr};
-    int32_t* h_counts = nullptr;       // pinned mirror of d_counts (source of the 4-byte async copies)
-    int h_counts_cap = 0;
-    int stage_next = 0;
-
-    // scratch for query uploads / pair mode / results
-    uint8_t* d_qbuf = nullptr;  size_t d_qbuf_bytes = 0;
-    int32_t* d_qcounts = nullptr; size_t d_qcounts_n = 0;
-    uint8_t* d_tbuf = nullptr;  size_t d_tbuf_bytes = 0;
-    int32_t* d_tcounts = nullptr; size_t d_tcounts_n = 0;
-    uint32_t* d_keys = nullptr; size_t d_keys_n = 0;
-    lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
-    lcm::WorkItem* d_items = nullptr; size_t d_items_n = 0;
-    std::vector<uint32_t> h_keys;
-    lcm_score* d_bulk_scores = nullptr; size_t d_bulk_scores_n = 0;   // lcm_all_vs_all_loops: scores stay on the device
-    size_t bulk_scores_valid = 0;                                     // records of the last fused call still in there
-    int32_t* d_meta = nullptr; size_t d_meta_n = 0;
-    lcm_loop_candidate* d_cands = nullptr; size_t d_cands_n = 0;
-
-    QuerySlot qslots[QUERY_SLOTS];
-    uint64_t db_generation = 1;        // bumped whenever stored frames are dropped (lcm_db_clear / lcm_db_load)
-    Plan plan;
-    lcm_launch_info info{};
-    bool info_pending = false;
-};
+void set_last_error(const char* msg) { last_error() = msg ? msg : ""; }
+}  // namespace lcm
 
 namespace {
 
 int set_device(const lcm_handle* h) {
     HIP_TRY(hipSetDevice(h->device));
-    return LCM_OK;
-}
-
-template <typename T>
-int ensure_dev(T*& p, size_t& have, size_t need, size_t slack_bytes = 0) {
-    if (need <= have && p) return LCM_OK;
-    if (p) HIP_TRY(hipFree(p));
-    p = nullptr; have = 0;
-    size_t n = std::max<size_t>(need, 16);
-    HIP_TRY(hipMalloc((void**)&p, n * sizeof(T) + slack_bytes));
-    have = n;
-    return LCM_OK;
-}
-
-template <typename T>
-int ensure_pinned(T*& p, size_t& have, size_t need) {
-    if (need <= have && p) return LCM_OK;
-    if (p) HIP_TRY(hipHostFree(p));
-    p = nullptr; have = 0;
-    const size_t n = std::max<size_t>(need, 16);
-    HIP_TRY(hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault));
-    have = n;
     return LCM_OK;
 }
 
@@ -320,7 +171,7 @@ void lcm_params_default(lcm_params* p) {
     p->sim_threshold = 0.15;
 }
 
-const char* lcm_last_error(void) { return g_err.c_str(); }
+const char* lcm_last_error(void) { return lcm::last_error().c_str(); }
 const char* lcm_backend_name(void) { return "hip-gfx950"; }
 
 int lcm_device_count(void) {
@@ -587,9 +438,9 @@ static int db_load_impl(lcm_handle* h, const char* path) {
     if (!rc) rc = lcm_sync(h);
     if (rc) {
         // an I/O or device error after the old contents were dropped: leave an EMPTY database, not half of one
-        const std::string why = g_err;
+        const std::string why = lcm::last_error();
         (void)lcm_db_clear(h);
-        g_err = why;
+        lcm::last_error() = why;
     }
     return rc;
 }
@@ -950,7 +801,8 @@ static int detect_loops_impl(lcm_handle* h, int current_frame_id, const uint8_t*
 static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
                    const int32_t* q_ids, int n_q_frames, int q_stride_rows,
                    void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets,
-                   uint32_t* d_idx_sums = nullptr) {
+                   uint32_t* d_idx_sums = nullptr, const uint32_t* q_frame_of = nullptr,
+                   const int32_t* h_query_counts = nullptr) {
     if (!h || !n_pairs) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     int rc = set_device(h); if (rc) return rc;
     const bool self = (d_query_rows == nullptr);
@@ -973,8 +825,12 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     std::vector<int32_t> qc;
     if (!self && n_q_frames > 0) {
         qc.resize((size_t)n_q_frames);
-        HIP_TRY(hipMemcpyAsync(qc.data(), d_query_counts, sizeof(int32_t) * (size_t)n_q_frames, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h_query_counts) {            // the caller (lcm_group_*) already knows them on the host
+            memcpy(qc.data(), h_query_counts, sizeof(int32_t) * (size_t)n_q_frames);
+        } else {
+            HIP_TRY(hipMemcpyAsync(qc.data(), d_query_counts, sizeof(int32_t) * (size_t)n_q_frames, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
         for (int c = 0; c < n_q_frames; ++c)
             if (qc[c] < 0 || qc[c] > q_stride_rows) return fail(LCM_ERR_INVALID_ARG, "query frame %d has %d rows, stride %d", c, qc[c], q_stride_rows);
     }
@@ -982,6 +838,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     key = mix(mix(key, self ? 1 : 2), (uint64_t)q_stride_rows);
     key = mix(key, h->db_generation);
     for (int i = 0; i < n_q_frames; ++i) key = mix(key, (uint64_t)(uint32_t)q_ids[i]);
+    if (q_frame_of) for (int i = 0; i < n_q_frames; ++i) key = mix(key, 0x51ull + q_frame_of[i]);
     for (int32_t c : qc) key = mix(key, (uint64_t)(uint32_t)c);
     if (!h->frames.empty()) key = mix(mix(key, (uint64_t)h->frames.front().id), (uint64_t)h->frames.back().id);
     if (key == 0) key = 1;
@@ -1005,7 +862,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
         for (int c = n_q_frames - 1; c >= 0; --c) {
             const int e = (int)(P.offsets[c + 1] - P.offsets[c]);
             for (int b = 0; b < e; b += chunk)
-                P.items.push_back({(uint32_t)c, (uint32_t)b, (uint32_t)std::min(chunk, e - b), (uint32_t)(P.offsets[c] + b)});
+                P.items.push_back({q_frame_of ? q_frame_of[c] : (uint32_t)c, (uint32_t)b, (uint32_t)std::min(chunk, e - b), (uint32_t)(P.offsets[c] + b)});
             if (self && e > 0) {
                 P.distances += (uint64_t)qn[c] * pre[e];
                 P.algo_bytes += pre[e] * 32 + (uint64_t)qn[c] * 32 + 8ull * e;
@@ -1065,6 +922,17 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     h->info.pairs = P.n_pairs; h->info.distances = P.distances; h->info.algo_bytes = P.algo_bytes;
     return LCM_OK;
 }
+
+}  // extern "C"  (reopened below)
+namespace lcm {
+int all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids,
+               int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, size_t* n_pairs,
+               size_t* pair_offsets, uint32_t* d_idx_sums, const uint32_t* q_frame_of, const int32_t* h_query_counts) {
+    return guarded([&] { return all_vs_all_impl(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, d_scores,
+                                                scores_cap, n_pairs, pair_offsets, d_idx_sums, q_frame_of, h_query_counts); });
+}
+}  // namespace lcm
+extern "C" {
 
 // Bulk loop search with the loop test fused on the device: all-vs-all scores stay in device memory, a second tiny
 // kernel applies README.md:123-126 per pair and compacts the candidates; only those cross PCIe.

@@ -1,0 +1,174 @@
+// lcm_internal.h — shared between the translation units of liblcm_hip.so (lcm_api.cpp, lcm_group.cpp): the handle,
+// its helpers and the error plumbing.  Not installed; the public surface is include/lcm.h.
+#pragma once
+#include "../../include/lcm.h"
+
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lcm_kernels.h"
+
+namespace lcm {
+// last error message of the calling thread (lcm_last_error()); `fail` formats it and returns `code`
+std::string& last_error();
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+void set_last_error(const char* msg);   // for the host-class shim (lcs_host.cpp)
+}  // namespace lcm
+
+namespace {
+using lcm::fail;
+
+// Nothing may throw across the C boundary (include/lcm.h): every entry point that touches a std container runs inside
+// this guard, which turns std::bad_alloc into LCM_ERR_OOM and anything else into LCM_ERR_HIP + message.
+template <typename F>
+int guarded(F&& f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(LCM_ERR_OOM, "host allocation failed (std::bad_alloc)"); }
+    catch (const std::exception& e) { return fail(LCM_ERR_HIP, "unexpected C++ exception: %s", e.what()); }
+    catch (...) { return fail(LCM_ERR_HIP, "unexpected C++ exception"); }
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? LCM_ERR_OOM : LCM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                \
+    } while (0)
+
+constexpr int ROW_PAD = 4;            // stored rows are padded to a multiple of 4 with copies of the last row
+constexpr size_t ARENA_SLACK = 512;   // the kernel prefetches up to 4 rows past a frame's padded end
+constexpr int DEFAULT_MAX_DESC = 2000;  // ORB nfeatures of the reference (README.md:114)
+constexpr int STAGE_BUFS = 2;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct FrameMeta {
+    int32_t id;
+    int32_t n;       // descriptor rows
+    int32_t n_kp;    // keypoints (similarity denominator)
+};
+
+constexpr int QUERY_SLOTS = 4;    // online queries that may be in flight at once (lcm_query_submit / _collect)
+
+struct QuerySlot {                // everything one in-flight online query owns
+    bool busy = false;
+    int n_elig = 0, nq = 0, query_id = 0;
+    uint64_t db_generation = 0;   // h->db_generation at submit: a clear / load in between invalidates the ticket
+    uint8_t* h_query = nullptr;   size_t h_query_bytes = 0;    // pinned staging of the query rows
+    lcm_score* h_scores = nullptr; size_t h_scores_n = 0;      // pinned landing zone of the score records
+    uint8_t* d_query = nullptr;   size_t d_query_bytes = 0;
+    lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
+    uint32_t* d_dist = nullptr;   size_t d_dist_n = 0;         // split mode: best distance per (pair, row)
+    hipEvent_t done = nullptr;
+};
+
+struct Plan {            // cached work list of one bulk call shape
+    uint64_t key = 0;    // hash of what it was built from
+    std::vector<lcm::WorkItem> items;
+    std::vector<size_t> offsets;    // per query frame, start of its run of pairs (n_q + 1)
+    lcm::WorkItem* d_items = nullptr;
+    size_t d_items_cap = 0;
+    size_t n_pairs = 0;
+    uint64_t distances = 0, algo_bytes = 0;
+    int max_q_rows = 0;
+};
+
+}  // namespace
+
+struct lcm_handle {
+    lcm_params params;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t db_ready = nullptr;     // last append landed (recorded on copy_stream)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_aux_start = nullptr, ev_aux_stop = nullptr;   // the follow-up kernel of a call (k_loop_test, ...)
+    bool aux_pending = false;
+    int variant = 0;
+    int tune_item_slots = 0;           // 0 = automatic (pick_chunk)
+    int tune_online_split = -1;        // -1 = automatic (enqueue_query)
+
+    // database arena
+    uint8_t* d_rows = nullptr;
+    int32_t* d_counts = nullptr;
+    int cap_frames = 0;
+    int stride_rows = 0;               // rows per frame slot (multiple of ROW_PAD)
+    std::vector<FrameMeta> frames;
+    bool pending_copy = false;
+
+    // pinned staging ring for streaming appends
+    uint8_t* h_stage[STAGE_BUFS] = {nullptr, nullptr};
+    size_t h_stage_bytes = 0;
+    hipEvent_t stage_done[STAGE_BUFS] = {nullptr, nullptr};
+    int32_t* h_counts = nullptr;       // pinned mirror of d_counts (source of the 4-byte async copies)
+    int h_counts_cap = 0;
+    int stage_next = 0;
+
+    // scratch for query uploads / pair mode / results
+    uint8_t* d_qbuf = nullptr;  size_t d_qbuf_bytes = 0;
+    int32_t* d_qcounts = nullptr; size_t d_qcounts_n = 0;
+    uint8_t* d_tbuf = nullptr;  size_t d_tbuf_bytes = 0;
+    int32_t* d_tcounts = nullptr; size_t d_tcounts_n = 0;
+    uint32_t* d_keys = nullptr; size_t d_keys_n = 0;
+    lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
+    lcm::WorkItem* d_items = nullptr; size_t d_items_n = 0;
+    std::vector<uint32_t> h_keys;
+    lcm_score* d_bulk_scores = nullptr; size_t d_bulk_scores_n = 0;   // lcm_all_vs_all_loops: scores stay on the device
+    size_t bulk_scores_valid = 0;                                     // records of the last fused call still in there
+    int32_t* d_meta = nullptr; size_t d_meta_n = 0;
+    lcm_loop_candidate* d_cands = nullptr; size_t d_cands_n = 0;
+
+    QuerySlot qslots[QUERY_SLOTS];
+    uint64_t db_generation = 1;        // bumped whenever stored frames are dropped (lcm_db_clear / lcm_db_load)
+    Plan plan;
+    lcm_launch_info info{};
+    bool info_pending = false;
+};
+
+
+namespace {
+
+template <typename T>
+int ensure_dev(T*& p, size_t& have, size_t need, size_t slack_bytes = 0) {
+    if (need <= have && p) return LCM_OK;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr; have = 0;
+    size_t n = std::max<size_t>(need, 16);
+    HIP_TRY(hipMalloc((void**)&p, n * sizeof(T) + slack_bytes));
+    have = n;
+    return LCM_OK;
+}
+
+template <typename T>
+int ensure_pinned(T*& p, size_t& have, size_t need) {
+    if (need <= have && p) return LCM_OK;
+    if (p) HIP_TRY(hipHostFree(p));
+    p = nullptr; have = 0;
+    const size_t n = std::max<size_t>(need, 16);
+    HIP_TRY(hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault));
+    have = n;
+    return LCM_OK;
+}
+
+}  // namespace
+
+namespace lcm {
+// Bulk search behind lcm_all_vs_all / lcm_all_vs_all_argmin.  q_frame_of (optional, n_q_frames entries): query frame c
+// lives at index q_frame_of[c] of d_query_rows / d_query_counts instead of index c (the group's rank-major gathered
+// query buffer).  h_query_counts (optional, host, indexed by c) spares the device read of the row counts.
+// d_idx_sums non-NULL selects the argmin kernel.
+int all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids,
+               int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, size_t* n_pairs,
+               size_t* pair_offsets, uint32_t* d_idx_sums, const uint32_t* q_frame_of, const int32_t* h_query_counts);
+}  // namespace lcm

@@ -79,4 +79,18 @@ struct LoopTestArgs {
 };
 hipError_t launch_loop_test(const LoopTestArgs& a, hipStream_t st);
 
+// Multi-GPU merge (lcm_group_*): the W per-shard score arrays, gathered back to back on one device, are un-permuted
+// into the single-device (query ascending, stored ascending) order.  Shard r's records are in (query ascending, owned
+// stored ascending) order; query c's k-th record of shard r is stored position r + k * W, so it lands at
+// offsets[c] + r + k * W.  HBM-bound: 8 bytes read + 8 bytes written per pair.
+struct MergeArgs {
+    const void*     gathered;      // all shards' lcm_score records, shard r at record index shard_base[r]
+    void*           merged;        // output, n_total records
+    const uint32_t* shard_offsets; // W arrays of n_q + 1 per-query offsets inside shard r (shard-local record index)
+    const uint32_t* offsets;       // n_q + 1 per-query offsets of the merged array
+    uint32_t        shard_base[9]; // W + 1 entries (W <= 8)
+    uint32_t        world, n_q, n_total;
+};
+hipError_t launch_merge_shards(const MergeArgs& a, hipStream_t st);
+
 }  // namespace lcm

@@ -624,6 +624,28 @@ hipError_t launch_loop_test(const LoopTestArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_merge_shards(MergeArgs a) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_total) return;
+    uint32_t r = 0;
+    while (r + 1 < a.world && i >= a.shard_base[r + 1]) ++r;
+    const uint32_t li = i - a.shard_base[r];
+    const uint32_t* off_r = a.shard_offsets + (size_t)r * (a.n_q + 1);
+    uint32_t lo = 0, hi = a.n_q;                      // last c with off_r[c] <= li
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off_r[mid] <= li) lo = mid; else hi = mid;
+    }
+    const uint32_t k = li - off_r[lo];
+    reinterpret_cast<uint2*>(a.merged)[a.offsets[lo] + r + k * a.world] = reinterpret_cast<const uint2*>(a.gathered)[i];
+}
+
+hipError_t launch_merge_shards(const MergeArgs& a, hipStream_t st) {
+    if (a.n_total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_shards, dim3((a.n_total + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 // variant 0: row-per-lane, bulk scoring tracks distances only (default)
 // variant 1: row-per-lane, bulk scoring tracks full (dist, idx) keys too (the kernel the pair mode always uses)
 // variant 2 / 3: north_star's train-row-per-lane mapping, distances only / keys (stored frames of <= 2048 rows)

@@ -117,6 +117,22 @@ def test_null_handle_calls_fail_cleanly(pkg):
     assert lib.lcm_dev_free(None, None) == -1
     assert lib.lcm_dev_upload(None, None, None, 0) == -1
     assert lib.lcm_dev_download(None, None, None, 0) == -1
+    g = C.c_void_p()
+    assert lib.lcm_group_create(C.byref(p), 1, None, None) == -1
+    assert lib.lcm_group_create(C.byref(p), 0, None, C.byref(g)) == -1 and not g.value
+    assert lib.lcm_group_size(None) == 0 and lib.lcm_group_db_size(None) == 0
+    assert lib.lcm_group_handle(None, 0, C.byref(g)) == -1
+    assert lib.lcm_group_set_params(None, C.byref(p)) == -1
+    assert lib.lcm_group_reserve(None, 1, 1) == -1
+    assert lib.lcm_group_append(None, 0, buf, 1, -1) == -1
+    assert lib.lcm_group_clear(None) == -1
+    assert lib.lcm_group_all_vs_all(None, None, 0, C.byref(z), None) == -1
+    assert lib.lcm_group_last_info(None, C.byref(pkg.capi.GroupInfo())) == -1
+    assert lib.lcm_group_query_scores(None, buf, 1, 0, buf, buf, 1, C.byref(n)) == -1
+    assert lib.lcm_group_detect_loops(None, 0, buf, 1, 1, buf, 1, C.byref(n)) == -1
+    assert lib.lcm_merge_shard_scores(None, None, 1, None, 0, 0, None, 0, C.byref(z), None) == -1
+    assert lib.lcm_merge_shard_scores_device(None, None, None, 1, None, 0, 0, None, 0, C.byref(z)) == -1
+    lib.lcm_group_destroy(None)                             # no-op
     lib.lcm_destroy(None)                                   # no-op
     assert b"" != lib.lcm_last_error()
     assert lib.lcm_create(C.byref(p), 0, None, None) == -1  # out == NULL

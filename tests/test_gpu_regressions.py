@@ -40,13 +40,18 @@ def test_plan_is_not_stale_when_external_query_counts_change(matcher, oracle, pk
         for counts in (np.full(fs.n_frames, 400, np.int32), fs.counts.copy(), np.full(fs.n_frames, 1100, np.int32)):
             matcher.dev_upload(d_counts, counts)
             got, offs, info = _bulk(matcher, pkg, d_rows, d_counts, fs.ids, fs.stride_rows)
-            k = 0
+            # expected: query frame c cut to counts[c] rows against the FULL stored frame i.  The oracle's tuned path
+            # takes one row-count array for both roles, so the cut queries are appended as extra frames.
+            pq, pt = [], []
             for c in range(fs.n_frames):
                 for i in range(fs.n_frames):
                     if fs.ids[c] - fs.ids[i] >= gap:
-                        assert got[k] == oracle.pair_score(fs.rows[c, : counts[c]], fs.frame(i), p), (c, i, counts[c])
-                        k += 1
-            assert k == len(got)
+                        pq.append(fs.n_frames + c); pt.append(i)
+            both_rows = np.concatenate([fs.rows, fs.rows])
+            both_counts = np.concatenate([fs.counts, counts]).astype(np.int32)
+            want, _, _ = oracle.fast_score_pairs(both_rows, both_counts, pq, pt, p, n_threads=8)
+            np.testing.assert_array_equal(got, want)
+            assert got[3] == oracle.pair_score(fs.rows[pq[3] - fs.n_frames, : counts[pq[3] - fs.n_frames]], fs.frame(pt[3]), p)
             infos.append(int(info.distances))
         assert infos[0] * 5 == infos[1] == pytest.approx(infos[2] * 2000 / 1100)      # the accounting follows too
     finally:
