@@ -68,84 +68,140 @@ def host_cores():
     return max(1, n)
 
 
-def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi, wl_desc, seed):
-    """Online mode: frames arrive one at a time as HOST rows.  Per frame: lcm_query_submit (pinned staging, H2D of the
-    64 KB query, kernel over this rank's shard, D2H of the 8-byte records — all enqueued, no host wait), then, if this
-    rank owns the frame's position, lcm_db_append (pinned staging + hipMemcpyAsync on the copy stream), then
-    lcm_query_collect of the PREVIOUS frame: one query is always in flight while the host prepares the next.
-    One step = one pass over the whole sequence.  Scores are gathered once per step (RCCL) when N > 1."""
+def cpu_baseline_sample(entry, pkg, fs, gap, offs, got, seconds, threads, shard=None):
+    """The oracle's tuned CPU path on a random sample of the workload's eligible pairs sized for ~`seconds` of CPU work;
+    `got` (optional) = the GPU's records in single-device order, compared on the same pairs (0 mismatches required).
+    shard = (rank, world): sample only pairs whose stored frame that rank owns; `got`/`offs` are then that shard's."""
+    oracle = entry.load_oracle()
+    oracle.build()
+    n_frames = fs.n_frames
+    rng = np.random.default_rng(123)
+    qs = rng.integers(gap, n_frames, size=262144)
+    ts = np.array([rng.integers(0, q - gap + 1) for q in qs])
+    if shard is not None:
+        r, w = shard
+        ts = ts - (ts % w) + r
+        ok = (ts >= 0) & (ts <= qs - gap)
+        qs, ts = qs[ok], ts[ok]
+    op = oracle.default_params(min_gap=gap)
+    n_cal = min(4 * threads, len(qs))
+    _, secs, isa = oracle.fast_score_pairs(fs.rows, fs.counts, qs[:n_cal], ts[:n_cal], op, threads)
+    n_s = int(min(len(qs), max(n_cal, seconds / max(secs / n_cal, 1e-9))))
+    cs, secs, isa = oracle.fast_score_pairs(fs.rows, fs.counts, qs[:n_s], ts[:n_s], op, threads)
+    cpu_dist = int(np.sum(fs.counts[qs[:n_s]].astype(np.int64) * fs.counts[ts[:n_s]].astype(np.int64)))
+    out = {"value": cpu_dist / secs, "unit": "distances/s", "cores": threads, "kind": "port",
+           "sample": f"{n_s} random eligible pairs of the same workload ({cpu_dist:.3e} distances, {secs:.1f} s), "
+                     f"oracle tuned path ({isa}, pthreads over pairs)"}
+    if got is not None:
+        local_t = ts[:n_s] if shard is None else (ts[:n_s] - shard[0]) // shard[1]
+        idx = offs[qs[:n_s]].astype(np.int64) + local_t
+        mismatch = int(np.sum(got[idx] != cs))
+        out["gpu_vs_cpu_sample_mismatches"] = mismatch
+        if mismatch:
+            print(f"PARITY FAILURE: {mismatch} of {n_s} sampled pairs differ from the CPU oracle", file=sys.stderr)
+    return out
+
+
+def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi, wl_desc, seed, entry):
+    """Online mode: frames arrive one at a time as HOST rows and are scored in micro-batches of --stream-batch frames
+    (lcm_query_submit_batch: pinned staging, ONE H2D of the batch's rows, ONE launch over this rank's shard, one D2H
+    of the 8-byte records — all enqueued, no host wait), then the frames this rank owns are appended (pinned ring +
+    hipMemcpyAsync on the copy stream, overlapping the launch just submitted), then the PREVIOUS batch is collected: one
+    batch is always in flight while the host prepares the next.  A batch spans fewer ids than min_gap, so the records
+    are exactly those of frame-by-frame processing.  One step = one pass over the whole sequence (database empty at the
+    start).  Scores are gathered once per step (RCCL) when N > 1."""
     p = pkg.default_params()
     p.min_gap = args.gap
+    B = max(1, min(args.stream_batch, 16))
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     m = pkg.Matcher(p, device=local_rank, stream=stream.cuda_stream)
     n_frames = fs.n_frames
+    assert B == 1 or int(fs.ids[min(B, n_frames) - 1] - fs.ids[0]) < max(args.gap, 1), "a batch must span fewer ids than min_gap"
     owned_n = len(pkg.sharding.owned_positions(n_frames, rank, world))
     m.reserve(owned_n, fs.stride_rows)
     frames = [np.ascontiguousarray(fs.frame(f)) for f in range(n_frames)]
+    ids = [int(x) for x in fs.ids]
     cdev = dev if args.backend == "nccl" else torch.device("cpu")
+    er = pkg.sharding.shard_eligible_counts(fs.ids, args.gap, rank, world)
+    cap = int(er.max()) * B if len(er) else 1
 
     def one_pass():
         m.clear()
-        out, dist_n = [], 0
-
-        def take(ticket, f):
-            nonlocal dist_n
-            sc, _ = m.query_collect(ticket)
-            out.append(sc)
-            dist_n += int(sc["n_train"].astype(np.int64).sum()) * frames[f].shape[0]
-
+        out = []
         prev = None
-        for f in range(n_frames):
-            t = m.query_submit(frames[f], int(fs.ids[f]))        # enqueued; the host moves on
-            if f % world == rank:
-                m.append(int(fs.ids[f]), frames[f])              # copy stream: overlaps the query just submitted
+        for f0 in range(0, n_frames, B):
+            fr = range(f0, min(f0 + B, n_frames))
+            t = m.query_submit_batch([frames[f] for f in fr], [ids[f] for f in fr])   # enqueued; the host moves on
+            for f in fr:
+                if f % world == rank:
+                    m.append(ids[f], frames[f])                 # copy stream: overlaps the launch just submitted
             if prev is not None:
-                take(*prev)                                      # results of the PREVIOUS frame
-            prev = (t, f)
+                out.append(m.query_collect_batch(prev, cap)[0])  # results of the PREVIOUS batch
+            prev = t
         if prev is not None:
-            take(*prev)
+            out.append(m.query_collect_batch(prev, cap)[0])
         m.sync()
-        local = np.concatenate(out) if out else np.zeros(0, pkg.capi.SCORE_DTYPE)
-        if multi:
-            t = torch.from_numpy(local.view(np.int64).copy()).to(cdev)
-            shards = pkg.sharding.all_gather_scores(t, len(local))
-        else:
-            shards = [local]
-        return shards, dist_n
+        return np.concatenate(out) if out else np.zeros(0, pkg.capi.SCORE_DTYPE)
 
     for _ in range(args.warmup):
         one_pass()
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
+    m.online_stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        shards, dist_n = one_pass()
+        local = one_pass()
+        if multi:
+            t = torch.from_numpy(local.view(np.int64).copy()).to(cdev)
+            shards = pkg.sharding.all_gather_scores(t, len(local))
+        else:
+            shards = [local]
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
     t1 = time.perf_counter()
+    st = m.online_stats()
     el = torch.tensor([t1 - t0], dtype=torch.float64, device=cdev)
-    tot = torch.tensor([dist_n], dtype=torch.int64, device=cdev)
+    tot = torch.tensor([int(st.distances), int(st.pairs), int(st.algo_bytes)], dtype=torch.int64, device=cdev)
     if multi:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed, total_dist = float(el.item()), int(tot.item())
-    merged, _ = pkg.sharding.merge_shard_scores(shards, fs.ids, args.gap)
-    assert len(merged) == pkg.synth.n_pairs_all_vs_all(n_frames, args.gap)
+    elapsed = float(el.item())
+    total_dist, total_pairs, total_bytes = (int(x) // args.steps for x in tot.tolist())     # per step, all ranks
+    merged, moffs = pkg.sharding.merge_shard_scores(shards, fs.ids, args.gap)
+    assert len(merged) == pkg.synth.n_pairs_all_vs_all(n_frames, args.gap) == total_pairs
     if rank == 0:
+        kern_s = st.kernel_ms * 1e-3                              # this rank, all timed steps
+        kern_rate = int(st.distances) / max(kern_s, 1e-12)
+        achieved = int(st.algo_bytes) / max(kern_s, 1e-12) / 1e9
+        cpu = None
+        if not multi and args.cpu_seconds > 0:
+            cpu = cpu_baseline_sample(entry, pkg, fs, args.gap, moffs, merged, args.cpu_seconds,
+                                      args.cpu_threads or host_cores())
         emit(({
             "metric": METRIC, "value": total_dist * args.steps / elapsed, "unit": "distances/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if args.workload == "auto" else "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "STREAMING (online append + per-frame query, host rows over PCIe): " + wl_desc,
+            "config": {"workload": "STREAMING (online append + micro-batched queries, host rows over PCIe): " + wl_desc,
                        "frames": n_frames, "descriptors_per_frame": fs.stride_rows, "min_gap": args.gap,
-                       "pairs_per_step": len(merged), "distances_per_step": total_dist, "seed": seed,
-                       "sharding": "cyclic by frame" if world > 1 else "none"},
-            "roofline": None, "cpu_baseline": None,
-            "note": "PCIe-inclusive online rate; the headline metric is the batch mode (inputs resident in HBM)"}))
+                       "pairs_per_step": total_pairs, "distances_per_step": total_dist, "seed": seed,
+                       "stream_batch": B, "sharding": "cyclic by frame" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_score_rowlane (online launches: score + k_finalize_pairs in split mode)",
+                         "kernel_ms": st.kernel_ms / max(int(st.launches), 1), "launches": int(st.launches),
+                         "kernel_ms_total": st.kernel_ms, "algorithmic_bytes_total": int(st.algo_bytes),
+                         "note": "HIP events around every online launch, summed by the library (lcm_online_stats_read); "
+                                 "VALU-bound path, see roofline_valu"},
+            "roofline_valu": {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
+                              "frac": kern_rate / VALU_PEAK_DIST_PER_S, "nominal_peak": VALU_NOMINAL_DIST_PER_S,
+                              "nominal_frac": kern_rate / VALU_NOMINAL_DIST_PER_S},
+            "device_busy_frac": kern_s / elapsed,
+            "cpu_baseline": cpu,
+            "note": "PCIe-inclusive online rate (value); the headline metric is the batch mode (inputs resident in HBM)"}))
     m.close()
     if multi:
         dist.destroy_process_group()
@@ -186,6 +242,28 @@ def cfg4_fused_extra(pkg, torch, dev, local_rank, gap):
     return out
 
 
+def group_extra(pkg, fs, gap, expect):
+    """The same cfg2 search through lcm_group_* (the multi-GPU entry of the C ABI) with the devices this process can
+    see used as ONE group of size 1: ncclCommInitAll, all-gather of the shard arena into the query buffer, search,
+    gather, device merge, one download.  Wall time of the whole call, host rows already appended."""
+    p = pkg.default_params()
+    p.min_gap = gap
+    with pkg.Group(p, n_devices=1) as g:
+        g.reserve(fs.n_frames, fs.stride_rows)
+        for f in range(fs.n_frames):
+            g.append(int(fs.ids[f]), fs.frame(f))
+        g.all_vs_all()                                           # warm-up (plan, buffers, RCCL channels)
+        t0 = time.perf_counter()
+        merged, _ = g.all_vs_all()
+        t1 = time.perf_counter()
+        gi = g.info()
+    return {"api": "lcm_group_all_vs_all", "n_devices": 1, "ms": (t1 - t0) * 1e3, "pairs": int(gi.pairs),
+            "value": int(gi.distances) / (t1 - t0), "unit": "distances/s", "kernel_ms_max": gi.kernel_ms_max,
+            "gather_merge_ms": gi.gather_merge_ms, "download_ms": gi.download_ms,
+            "allgather_query_bytes": int(gi.gathered_query_bytes),
+            "equals_single_handle_result": bool(expect is not None and len(merged) == len(expect) and np.array_equal(merged, expect))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +278,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores this process may use")
     ap.add_argument("--mode", default="batch", help="batch (default: one all-vs-all pass per step) | stream (online: "
                     "per frame, score it against the database, then append it — BASELINE.json configs[4] shape)")
+    ap.add_argument("--stream-batch", type=int, default=8, help="--mode stream: frames per micro-batch (1..16; 1 = frame by frame)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra blocks of the default N = 1 line (cfg4 fused step)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the N > 1 code path (process group, all-gather) even at world size 1")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU rehearsal of the N > 1 path)")
@@ -265,7 +344,7 @@ def main():
     fs = pkg.synth.make_frames(n_frames, n_desc, seed=seed)
 
     if args.mode == "stream":
-        return stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi, wl_desc, seed)
+        return stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi, wl_desc, seed, entry)
 
     # ---- inputs resident in HBM ----------------------------------------------------------------------
     d_rows = torch.from_numpy(fs.rows).to(dev)                 # (frames, stride, 32) uint8: the query stream
@@ -398,30 +477,9 @@ def main():
     if fused:
         fused_scores = m.last_bulk_scores()                  # what the fused call left in HBM (parity sample below)
     if rank == 0 and not multi and args.cpu_seconds > 0:
-        oracle = entry.load_oracle()
-        oracle.build()
-        threads = args.cpu_threads or host_cores()
-        rng = np.random.default_rng(123)
-        got = np.zeros(n_local, pkg.capi.SCORE_DTYPE)
         torch.cuda.synchronize(dev)
-        got[:] = fused_scores if fused else scores.cpu().numpy().view(pkg.capi.SCORE_DTYPE)[:n_local]
-        qs = rng.integers(args.gap, n_frames, size=262144)
-        ts = np.array([rng.integers(0, q - args.gap + 1) for q in qs])
-        op = oracle.default_params(min_gap=args.gap)
-        # calibrate on a few pairs, then size the sample for ~cpu_seconds of CPU work
-        n_cal = min(4 * threads, len(qs))
-        _, secs, isa = oracle.fast_score_pairs(fs.rows, fs.counts, qs[:n_cal], ts[:n_cal], op, threads)
-        n_s = int(min(len(qs), max(n_cal, args.cpu_seconds / max(secs / n_cal, 1e-9))))
-        cs, secs, isa = oracle.fast_score_pairs(fs.rows, fs.counts, qs[:n_s], ts[:n_s], op, threads)
-        cpu_dist = int(np.sum(fs.counts[qs[:n_s]].astype(np.int64) * fs.counts[ts[:n_s]].astype(np.int64)))
-        idx = offs[qs[:n_s]].astype(np.int64) + ts[:n_s]          # W == 1: slot == frame position
-        mismatch = int(np.sum(got[idx] != cs))
-        cpu = {"value": cpu_dist / secs, "unit": "distances/s", "cores": threads, "kind": "port",
-               "sample": f"{n_s} random eligible pairs of the same workload ({cpu_dist:.3e} distances, {secs:.1f} s), "
-                         f"oracle tuned path ({isa}, pthreads over pairs)",
-               "gpu_vs_cpu_sample_mismatches": mismatch}
-        if mismatch:
-            print(f"PARITY FAILURE: {mismatch} of {n_s} sampled pairs differ from the CPU oracle", file=sys.stderr)
+        got = fused_scores if fused else scores.cpu().numpy().view(pkg.capi.SCORE_DTYPE)[:n_local]
+        cpu = cpu_baseline_sample(entry, pkg, fs, args.gap, offs, got, args.cpu_seconds, args.cpu_threads or host_cores())
 
     if rank == 0:
         traffic = None
@@ -472,10 +530,12 @@ def main():
                             "note": "roofline.kernel_ms is the score kernel inside the fused call; ms_per_step covers "
                                     "score kernel + k_loop_test + candidate download + host sort"}
         if not multi and args.workload == "auto" and not args.frames and not args.desc and not args.no_extras:
+            single = scores.cpu().numpy().view(pkg.capi.SCORE_DTYPE)[:n_local].copy()
             m.close()
             del scores, d_rows
             torch.cuda.empty_cache()
-            out["extra"] = {"cfg4_fused": cfg4_fused_extra(pkg, torch, dev, local_rank, args.gap)}
+            out["extra"] = {"group_of_one": group_extra(pkg, fs, args.gap, single),
+                            "cfg4_fused": cfg4_fused_extra(pkg, torch, dev, local_rank, args.gap)}
         emit(out)
     m.close()
     if multi:

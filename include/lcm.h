@@ -109,6 +109,13 @@ typedef struct lcm_launch_info {
                                  * lcm_all_vs_all_loops */
 } lcm_launch_info;
 
+/* Totals over the online queries COLLECTED so far on a handle (single and batched): device time of their kernels from
+ * HIP events on the launch stream, and the work they did — what a streaming run's roofline is computed from. */
+typedef struct lcm_online_stats {
+    double   kernel_ms;
+    uint64_t launches, queries, pairs, distances, algo_bytes;
+} lcm_online_stats;
+
 typedef struct lcm_handle lcm_handle;
 
 LCM_API void        lcm_params_default(lcm_params* p);
@@ -171,6 +178,16 @@ LCM_API int  lcm_query_scores(lcm_handle* h, const uint8_t* query, int nq, int q
  * out_frame_ids).  Frames appended after the submit are not part of its answer. */
 LCM_API int  lcm_query_submit(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, int* ticket);
 LCM_API int  lcm_query_collect(lcm_handle* h, int ticket, lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out);
+/* Micro-batched online queries (streaming mode at full device rate): up to 16 frames — e.g. the last few camera frames,
+ * none of them appended yet — are scored by ONE launch, each against the stored frames with its_id - id >= min_gap as the
+ * database stands at submit time.  (With min_gap >= the id span of the batch this equals submitting them one by one,
+ * each before its predecessors are appended.)  One ticket for the batch; lcm_query_collect_batch returns the records of
+ * all queries back to back (query 0's first) and, optionally, offsets[n_queries + 1]. */
+LCM_API int  lcm_query_submit_batch(lcm_handle* h, const uint8_t* const* queries, const int* nq, const int* query_frame_ids,
+                                    int n_queries, int* ticket);
+LCM_API int  lcm_query_collect_batch(lcm_handle* h, int ticket, lcm_score* out_scores, size_t cap, size_t* n_out,
+                                     size_t* offsets);
+LCM_API int  lcm_online_stats_read(lcm_handle* h, lcm_online_stats* out, int reset);
 /* detectLoops for a frame that is already stored (or given explicitly with query != NULL). */
 LCM_API int  lcm_detect_loops(lcm_handle* h, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
                               lcm_loop_candidate* out, int cap, int* n_out);

@@ -49,6 +49,11 @@ class LaunchInfo(C.Structure):
                 ("aux_kernel_ms", C.c_double)]
 
 
+class OnlineStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_uint64), ("queries", C.c_uint64), ("pairs", C.c_uint64),
+                ("distances", C.c_uint64), ("algo_bytes", C.c_uint64)]
+
+
 class GroupInfo(C.Structure):
     _fields_ = [("n_devices", C.c_int32), ("pairs", C.c_uint64), ("distances", C.c_uint64), ("algo_bytes", C.c_uint64),
                 ("kernel_ms_max", C.c_double), ("gather_merge_ms", C.c_double), ("download_ms", C.c_double),
@@ -95,6 +100,9 @@ _SIGNATURES = {
     "lcm_query_scores": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _i32p]),
     "lcm_query_submit": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i32p]),
     "lcm_query_collect": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i32p]),
+    "lcm_query_submit_batch": (C.c_int, [_vp, _vp, _i32p, _i32p, C.c_int, _i32p]),
+    "lcm_query_collect_batch": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
+    "lcm_online_stats_read": (C.c_int, [_vp, C.POINTER(OnlineStats), C.c_int]),
     "lcm_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
     "lcm_loop_test": (C.c_int, [C.POINTER(Params), C.POINTER(Score), C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lcm_all_vs_all": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
@@ -314,6 +322,37 @@ class Matcher:
         _check(self._lib.lcm_query_collect(self._h, ticket, scores.ctypes.data_as(_vp), ids.ctypes.data_as(_vp), cap,
                                            C.byref(n)))
         return scores[: n.value], ids[: n.value]
+
+    def query_submit_batch(self, queries: Sequence[np.ndarray], query_frame_ids: Sequence[int]) -> int:
+        """Up to 16 query frames scored by ONE launch against the database as it stands now; returns one ticket."""
+        qs = [_rows(q) for q in queries]
+        B = len(qs)
+        ptrs = (_vp * B)(*[q.ctypes.data if q.shape[0] else None for q in qs])
+        nq = np.array([q.shape[0] for q in qs], np.int32)
+        ids = np.ascontiguousarray(query_frame_ids, np.int32)
+        assert ids.shape[0] == B
+        t = C.c_int32(-1)
+        _check(self._lib.lcm_query_submit_batch(self._h, ptrs, nq.ctypes.data_as(_i32p), ids.ctypes.data_as(_i32p), B,
+                                                C.byref(t)))
+        self._batch_sizes = getattr(self, "_batch_sizes", {})
+        self._batch_sizes[t.value] = B
+        return t.value
+
+    def query_collect_batch(self, ticket: int, cap: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """(records of all the batch's queries back to back, offsets[B + 1])."""
+        B = self._batch_sizes[ticket]
+        cap = max(len(self), 1) * B if cap is None else cap
+        scores = np.zeros(max(cap, 1), SCORE_DTYPE)
+        offs = np.zeros(B + 1, np.uintp)
+        n = C.c_size_t(0)
+        _check(self._lib.lcm_query_collect_batch(self._h, ticket, scores.ctypes.data_as(_vp), cap, C.byref(n),
+                                                 offs.ctypes.data_as(_vp)))
+        return scores[: n.value], offs
+
+    def online_stats(self, reset: bool = False) -> OnlineStats:
+        st = OnlineStats()
+        _check(self._lib.lcm_online_stats_read(self._h, C.byref(st), 1 if reset else 0))
+        return st
 
     def detect_loops(self, current_frame_id: int, query=None, n_keypoints: int = -1) -> np.ndarray:
         cap = max(len(self), 1)

@@ -230,6 +230,8 @@ void lcm_destroy(lcm_handle* h) {
         if (q.h_query) (void)hipHostFree(q.h_query);
         if (q.h_scores) (void)hipHostFree(q.h_scores);
         if (q.done) (void)hipEventDestroy(q.done);
+        if (q.k0) (void)hipEventDestroy(q.k0);
+        if (q.k1) (void)hipEventDestroy(q.k1);
     }
     for (int i = 0; i < STAGE_BUFS; ++i) {
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
@@ -617,7 +619,8 @@ static void account_prefix(lcm_handle* h, int nq, int n_elig) {
 // implicit (derived from blockIdx), so nothing but the query itself crosses PCIe.  Short databases use the split
 // mode (lcm_kernels.hip): 2 / 4 / 8 workgroups per pair + the on-device fold.
 static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int nq, int n_elig) {
-    q.n_elig = n_elig; q.nq = nq;
+    q.n_elig = n_elig; q.nq = nq; q.n_batch = 0;
+    q.acc_pairs = q.acc_distances = q.acc_bytes = 0; q.acc_launches = 0; q.acc_queries = 1;
     if (n_elig <= 0) { HIP_TRY(hipEventRecord(q.done, h->stream)); return LCM_OK; }
     int rc = wait_db(h); if (rc) return rc;
     const int split_env = h->tune_online_split;              // lcm_set_tuning(LCM_TUNE_ONLINE_SPLIT); -1 = automatic
@@ -638,6 +641,7 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
     a.imp_nq = nq; a.imp_total = (uint32_t)n_elig;
     HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    HIP_TRY(hipEventRecord(q.k0, h->stream));
     if (qpt == 1 || qpt == 2 || qpt == 4) {
         const int chunk_rows = 256 * qpt;
         const int n_chunks = (nq + chunk_rows - 1) / chunk_rows;
@@ -666,11 +670,120 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
         h->info.launches = 1; h->info.workgroups = n_items;
     }
     HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    HIP_TRY(hipEventRecord(q.k1, h->stream));
     h->info_pending = true;
     account_prefix(h, nq, n_elig);
+    q.acc_pairs = h->info.pairs; q.acc_distances = h->info.distances; q.acc_bytes = h->info.algo_bytes;
+    q.acc_launches = h->info.launches; q.acc_queries = 1;
     HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(q.done, h->stream));
     return LCM_OK;
+}
+
+// Micro-batch of online queries: B query frames (already in device memory at d_q, query b at row b * rows_per_query)
+// against stored slots [0, elig[b]) each, ONE score launch (+ one finalize launch in split mode), one download.
+// A launch of B x n_elig pairs fills the chip where a single query's few hundred pairs leave its tail idle, and the
+// host pays one submit / collect round trip per B frames.
+static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int rows_per_query, int B, const int* nq, const int* elig) {
+    size_t total = 0;
+    int max_nq = 0;
+    for (int b = 0; b < B; ++b) { total += (size_t)elig[b]; max_nq = std::max(max_nq, nq[b]); q.bat_elig[b] = elig[b]; }
+    q.n_batch = B; q.n_elig = (int)total; q.nq = max_nq;
+    q.acc_pairs = q.acc_distances = q.acc_bytes = 0; q.acc_launches = 0; q.acc_queries = (uint32_t)B;
+    if (total == 0) { HIP_TRY(hipEventRecord(q.done, h->stream)); return LCM_OK; }
+    if (total > 0x7FFFFFFFull) return fail(LCM_ERR_CAPACITY, "more than 2^31 pairs in one batch");
+    int rc = wait_db(h); if (rc) return rc;
+    int qpt = 0;
+    if (max_nq > 512) {
+        if (h->tune_online_split >= 0) qpt = h->tune_online_split;
+        else if (total < 1536) qpt = 1;          // same rule as a single query, on the batch's total pair count
+        else if (total < 6144) qpt = 2;
+        else if (total < 12288) qpt = 4;
+    }
+    rc = ensure_dev(q.d_scores, q.d_scores_n, total); if (rc) return rc;
+    rc = ensure_pinned(q.h_scores, q.h_scores_n, total); if (rc) return rc;
+    lcm::ScoreArgs a{};
+    a.q_rows = d_q; a.q_counts = nullptr; a.items = nullptr;
+    a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
+    a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
+    a.imp_nbatch = (uint32_t)B;
+    const bool split = (qpt == 1 || qpt == 2 || qpt == 4);
+    const int chunk_rows = split ? 256 * qpt : rows_per_query;
+    const int n_chunks = split ? (max_nq + chunk_rows - 1) / chunk_rows : 1;
+    if (rows_per_query % chunk_rows != 0 || n_chunks * chunk_rows > rows_per_query)
+        return fail(LCM_ERR_INVALID_ARG, "batch staging pitch %d does not fit %d chunks of %d rows", rows_per_query, n_chunks, chunk_rows);
+    const int spi = split ? 1 : (total >= 16384 ? 4 : (total >= 8192 ? 2 : 1));
+    // every query occupies rows_per_query rows of the staging buffer = rows_per_query / chunk_rows chunk slots, of
+    // which the first n_chunks are scored
+    const uint32_t chunk_slots = (uint32_t)(rows_per_query / chunk_rows);
+    a.q_stride_words = (uint32_t)chunk_rows * LCM_DESC_WORDS;
+    a.imp_chunks = (uint32_t)n_chunks; a.imp_chunk_rows = (uint32_t)chunk_rows; a.imp_spi = (uint32_t)spi;
+    uint32_t wg = 0, pair = 0;
+    for (int b = 0; b < B; ++b) {
+        a.bat_wg[b] = wg; a.bat_pair[b] = pair;
+        a.bat_nq[b] = nq[b]; a.bat_elig[b] = (uint32_t)elig[b];
+        wg += (uint32_t)((elig[b] + spi - 1) / spi) * (uint32_t)n_chunks;
+        pair += (uint32_t)elig[b];
+    }
+    a.bat_wg[B] = wg; a.bat_pair[B] = pair;
+    // chunk index of query b's chunk c is b * imp_chunks + c in the kernel; with a pitch of chunk_slots chunks per query
+    // that only holds when imp_chunks == chunk_slots: the staging copy below packs the queries at that pitch
+    if ((uint32_t)n_chunks != chunk_slots) return fail(LCM_ERR_HIP, "internal: batch pitch %u != %d chunks", chunk_slots, n_chunks);
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    HIP_TRY(hipEventRecord(q.k0, h->stream));
+    if (split) {
+        rc = ensure_dev(q.d_dist, q.d_dist_n, total * (size_t)n_chunks * chunk_rows); if (rc) return rc;
+        a.scores = nullptr; a.keys = q.d_dist; a.keys_stride = (uint32_t)chunk_rows;
+        hipError_t e = lcm::launch_score_split(a, wg, qpt, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        lcm::FinalizeArgs f{};
+        f.dist = q.d_dist; f.padded_rows = (uint32_t)(n_chunks * chunk_rows); f.nq = 0;
+        f.db_counts = h->d_counts; f.slot_begin = 0; f.scores = q.d_scores;
+        f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
+        f.n_batch = (uint32_t)B;
+        for (int b = 0; b <= B; ++b) f.bat_pair[b] = a.bat_pair[b];
+        for (int b = 0; b < B; ++b) f.bat_nq[b] = nq[b];
+        e = lcm::launch_finalize(f, pair, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
+        h->info.launches = 2;
+    } else {
+        a.scores = q.d_scores; a.keys = nullptr; a.keys_stride = 0;
+        hipError_t e = lcm::launch_score(a, wg, max_nq, false, h->variant >= 2 ? 0 : h->variant, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        h->info.launches = 1;
+    }
+    h->info.workgroups = wg;
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    HIP_TRY(hipEventRecord(q.k1, h->stream));
+    h->info_pending = true;
+    {
+        uint64_t dist = 0, bytes = 0, prows = 0;
+        int s = 0;
+        std::vector<std::pair<int, int>> order((size_t)B);      // queries by eligibility, to walk the prefix sums once
+        for (int b = 0; b < B; ++b) order[(size_t)b] = {elig[b], b};
+        std::sort(order.begin(), order.end());
+        for (auto [e, b] : order) {
+            for (; s < e; ++s) prows += (uint64_t)h->frames[(size_t)s].n;
+            dist += (uint64_t)nq[b] * prows;
+            bytes += prows * 32 + (uint64_t)nq[b] * 32 + 8ull * (uint64_t)e;
+        }
+        h->info.pairs = total; h->info.distances = dist; h->info.algo_bytes = bytes;
+        q.acc_pairs = total; q.acc_distances = dist; q.acc_bytes = bytes; q.acc_launches = h->info.launches;
+    }
+    HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(q.done, h->stream));
+    return LCM_OK;
+}
+
+// A finished query (its `done` event has been waited for) joins the handle's online totals.
+static void fold_online_stats(lcm_handle* h, QuerySlot& q) {
+    if (q.acc_launches) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, q.k0, q.k1) == hipSuccess) h->online.kernel_ms += ms; else (void)hipGetLastError();
+    }
+    h->online.launches += q.acc_launches; h->online.queries += q.acc_queries;
+    h->online.pairs += q.acc_pairs; h->online.distances += q.acc_distances; h->online.algo_bytes += q.acc_bytes;
+    q.acc_launches = 0; q.acc_queries = 0; q.acc_pairs = q.acc_distances = q.acc_bytes = 0;
 }
 
 static int find_slot(const lcm_handle* h, int frame_id) {
@@ -683,6 +796,8 @@ static int acquire_query_slot(lcm_handle* h, int* ticket) {
     for (int i = 0; i < QUERY_SLOTS; ++i)
         if (!h->qslots[i].busy) {
             if (!h->qslots[i].done) HIP_TRY(hipEventCreateWithFlags(&h->qslots[i].done, hipEventDisableTiming));
+            if (!h->qslots[i].k0) HIP_TRY(hipEventCreate(&h->qslots[i].k0));
+            if (!h->qslots[i].k1) HIP_TRY(hipEventCreate(&h->qslots[i].k1));
             *ticket = i;
             return LCM_OK;
         }
@@ -715,6 +830,7 @@ static int query_submit_impl(lcm_handle* h, const uint8_t* query, int nq, int qu
 
 static int query_collect_impl(lcm_handle* h, int ticket, lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out) {
     if (!h || !n_out || ticket < 0 || ticket >= QUERY_SLOTS || !h->qslots[ticket].busy) return fail(LCM_ERR_INVALID_ARG, "bad ticket");
+    if (h->qslots[ticket].n_batch > 0) return fail(LCM_ERR_INVALID_ARG, "ticket %d is a batch: use lcm_query_collect_batch", ticket);
     *n_out = 0;
     int rc = set_device(h); if (rc) return rc;
     QuerySlot& q = h->qslots[ticket];
@@ -735,6 +851,79 @@ static int query_collect_impl(lcm_handle* h, int ticket, lcm_score* out_scores, 
     }
     *n_out = q.n_elig;
     q.busy = false;
+    fold_online_stats(h, q);
+    return LCM_OK;
+}
+
+static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries, const int* nq, const int* query_frame_ids,
+                                   int n_queries, int* ticket) {
+    if (!h || !ticket || !queries || !nq || !query_frame_ids) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    *ticket = -1;
+    if (n_queries < 1 || n_queries > lcm::MAX_QUERY_BATCH) return fail(LCM_ERR_INVALID_ARG, "a batch holds 1..%d queries", lcm::MAX_QUERY_BATCH);
+    int max_nq = 0;
+    for (int b = 0; b < n_queries; ++b) {
+        if (nq[b] < 0 || (nq[b] > 0 && !queries[b])) return fail(LCM_ERR_INVALID_ARG, "query %d: bad rows", b);
+        if (nq[b] > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+        max_nq = std::max(max_nq, nq[b]);
+    }
+    int rc = set_device(h); if (rc) return rc;
+    int t = -1;
+    rc = acquire_query_slot(h, &t); if (rc) return rc;
+    QuerySlot& q = h->qslots[t];
+    q.query_id = query_frame_ids[0];
+    int elig[lcm::MAX_QUERY_BATCH];
+    size_t total = 0;
+    for (int b = 0; b < n_queries; ++b) { elig[b] = eligible_prefix(h, query_frame_ids[b], h->params.min_gap); total += (size_t)elig[b]; }
+    // staging pitch: every query gets the same number of rows, a whole number of the chunks enqueue_batch will cut
+    int pitch = std::max(max_nq, 1);
+    {
+        int qpt = 0;
+        if (max_nq > 512) {
+            if (h->tune_online_split >= 0) qpt = h->tune_online_split;
+            else if (total < 1536) qpt = 1;
+            else if (total < 6144) qpt = 2;
+            else if (total < 12288) qpt = 4;
+        }
+        if (qpt == 1 || qpt == 2 || qpt == 4) pitch = round_up(max_nq, 256 * qpt);
+    }
+    const size_t bytes = (size_t)pitch * (size_t)n_queries * LCM_DESC_BYTES;
+    rc = ensure_pinned(q.h_query, q.h_query_bytes, bytes); if (rc) return rc;
+    rc = ensure_dev(q.d_query, q.d_query_bytes, bytes, ARENA_SLACK); if (rc) return rc;
+    if (total > 0) {
+        for (int b = 0; b < n_queries; ++b)          // the callers' buffers are free when we return
+            if (nq[b] > 0) memcpy(q.h_query + (size_t)b * pitch * LCM_DESC_BYTES, queries[b], (size_t)nq[b] * LCM_DESC_BYTES);
+        HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    rc = enqueue_batch(h, q, (const uint32_t*)q.d_query, pitch, n_queries, nq, elig); if (rc) return rc;
+    q.busy = true;
+    q.db_generation = h->db_generation;
+    *ticket = t;
+    return LCM_OK;
+}
+
+static int query_collect_batch_impl(lcm_handle* h, int ticket, lcm_score* out_scores, size_t cap, size_t* n_out, size_t* offsets) {
+    if (!h || !n_out || ticket < 0 || ticket >= QUERY_SLOTS || !h->qslots[ticket].busy || h->qslots[ticket].n_batch <= 0)
+        return fail(LCM_ERR_INVALID_ARG, "bad batch ticket");
+    *n_out = 0;
+    int rc = set_device(h); if (rc) return rc;
+    QuerySlot& q = h->qslots[ticket];
+    if (q.db_generation != h->db_generation) {
+        (void)hipEventSynchronize(q.done);
+        q.busy = false; q.n_batch = 0;
+        return fail(LCM_ERR_NOT_FOUND, "ticket %d was submitted before lcm_db_clear / lcm_db_load: its result is void", ticket);
+    }
+    HIP_TRY(hipEventSynchronize(q.done));
+    if ((size_t)q.n_elig > cap) return fail(LCM_ERR_CAPACITY, "%d score records but room for %zu (the ticket stays valid)", q.n_elig, cap);
+    if (q.n_elig > 0 && !out_scores) return fail(LCM_ERR_INVALID_ARG, "out_scores is NULL (the ticket stays valid)");
+    if (q.n_elig > 0) memcpy(out_scores, q.h_scores, sizeof(lcm_score) * (size_t)q.n_elig);
+    if (offsets) {
+        size_t o = 0;
+        for (int b = 0; b < q.n_batch; ++b) { offsets[b] = o; o += (size_t)q.bat_elig[b]; }
+        offsets[q.n_batch] = o;
+    }
+    *n_out = (size_t)q.n_elig;
+    q.busy = false; q.n_batch = 0;
+    fold_online_stats(h, q);
     return LCM_OK;
 }
 
@@ -777,6 +966,7 @@ static int detect_loops_impl(lcm_handle* h, int current_frame_id, const uint8_t*
     QuerySlot& q = h->qslots[t];
     q.busy = false;                                  // the ticket never leaves this function, whatever happens below
     HIP_TRY(hipEventSynchronize(q.done));
+    fold_online_stats(h, q);
     int k = 0, total = 0;
     for (int s = 0; s < q.n_elig; ++s) {
         double sim;
@@ -1026,6 +1216,13 @@ int lcm_last_launch_info(const lcm_handle* hc, lcm_launch_info* info) {
     return LCM_OK;
 }
 
+int lcm_online_stats_read(lcm_handle* h, lcm_online_stats* out, int reset) {
+    if (!h || !out) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    *out = h->online;
+    if (reset) h->online = lcm_online_stats{};
+    return LCM_OK;
+}
+
 int lcm_last_bulk_scores(const lcm_handle* h, const void** d_scores, size_t* n_records) {
     if (!h || !d_scores || !n_records) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
     *d_scores = h->bulk_scores_valid ? h->d_bulk_scores : nullptr;
@@ -1093,6 +1290,12 @@ int lcm_query_submit(lcm_handle* h, const uint8_t* query, int nq, int query_fram
 }
 int lcm_query_collect(lcm_handle* h, int ticket, lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out) {
     return guarded([&] { return query_collect_impl(h, ticket, out_scores, out_frame_ids, cap, n_out); });
+}
+int lcm_query_submit_batch(lcm_handle* h, const uint8_t* const* queries, const int* nq, const int* query_frame_ids, int n_queries, int* ticket) {
+    return guarded([&] { return query_submit_batch_impl(h, queries, nq, query_frame_ids, n_queries, ticket); });
+}
+int lcm_query_collect_batch(lcm_handle* h, int ticket, lcm_score* out_scores, size_t cap, size_t* n_out, size_t* offsets) {
+    return guarded([&] { return query_collect_batch_impl(h, ticket, out_scores, cap, n_out, offsets); });
 }
 int lcm_query_scores(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, lcm_score* out_scores, int32_t* out_frame_ids, int* n_out) {
     return guarded([&] { return query_scores_impl(h, query, nq, query_frame_id, out_scores, out_frame_ids, n_out); });

@@ -64,12 +64,17 @@ struct QuerySlot {                // everything one in-flight online query owns
     bool busy = false;
     int n_elig = 0, nq = 0, query_id = 0;
     uint64_t db_generation = 0;   // h->db_generation at submit: a clear / load in between invalidates the ticket
+    int n_batch = 0;              // > 0: a micro-batch (lcm_query_submit_batch); n_elig = records of all its queries
+    int bat_elig[lcm::MAX_QUERY_BATCH] = {0};
     uint8_t* h_query = nullptr;   size_t h_query_bytes = 0;    // pinned staging of the query rows
     lcm_score* h_scores = nullptr; size_t h_scores_n = 0;      // pinned landing zone of the score records
     uint8_t* d_query = nullptr;   size_t d_query_bytes = 0;
     lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
     uint32_t* d_dist = nullptr;   size_t d_dist_n = 0;         // split mode: best distance per (pair, row)
     hipEvent_t done = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr;      // around this query's kernel(s): summed into the handle's online stats
+    uint64_t acc_pairs = 0, acc_distances = 0, acc_bytes = 0;
+    uint32_t acc_launches = 0, acc_queries = 0;
 };
 
 struct Plan {            // cached work list of one bulk call shape
@@ -130,6 +135,7 @@ struct lcm_handle {
     lcm_loop_candidate* d_cands = nullptr; size_t d_cands_n = 0;
 
     QuerySlot qslots[QUERY_SLOTS];
+    lcm_online_stats online{};         // totals over collected online queries (lcm_online_stats_read)
     uint64_t db_generation = 1;        // bumped whenever stored frames are dropped (lcm_db_clear / lcm_db_load)
     Plan plan;
     lcm_launch_info info{};

@@ -8,6 +8,7 @@ namespace lcm {
 constexpr int KEY_SHIFT = 22;                       // packed key = dist << 22 | train_idx  (dist <= 256 -> 9 bits)
 constexpr uint32_t KEY_IDX_MASK = (1u << KEY_SHIFT) - 1;
 constexpr int MAX_FUSED_QUERY_ROWS = 2048;          // one workgroup holds a whole query frame in registers
+constexpr int MAX_QUERY_BATCH = 16;                 // online queries scored by one launch (lcm_query_submit_batch)
 
 // One unit of work: query frame `q_frame` against stored slots [slot_begin, slot_begin + n_slots),
 // score records written to scores[out_offset ...].
@@ -37,6 +38,15 @@ struct ScoreArgs {
     // Workgroup b: chunk c = b % imp_chunks, run g = b / imp_chunks, out_offset = g * imp_spi * imp_chunks + c.
     uint32_t        imp_chunks, imp_chunk_rows, imp_spi, imp_total;
     int32_t         imp_nq;
+    // Implicit BATCH (items == NULL, imp_nbatch > 0): imp_nbatch query frames (micro-batched online queries), query b
+    // of bat_nq[b] rows stored at chunk index b * imp_chunks of q_rows, scored against stored slots [0, bat_elig[b]);
+    // its workgroups are [bat_wg[b], bat_wg[b + 1]) and its records start at pair index bat_pair[b].  imp_chunks,
+    // imp_chunk_rows and imp_spi are shared by the whole batch.
+    uint32_t        imp_nbatch;
+    uint32_t        bat_wg[MAX_QUERY_BATCH + 1];
+    uint32_t        bat_pair[MAX_QUERY_BATCH + 1];
+    int32_t         bat_nq[MAX_QUERY_BATCH];
+    uint32_t        bat_elig[MAX_QUERY_BATCH];
 };
 
 // Launch the pair-scoring kernel over n_items work items.  max_query_rows = largest row count of any query
@@ -50,11 +60,16 @@ hipError_t launch_score_split(const ScoreArgs& a, uint32_t n_items, int qpt, hip
 struct FinalizeArgs {
     const uint32_t* dist;        // best distance per (pair, row): dist[pair * padded_rows + row]
     uint32_t        padded_rows;
-    int32_t         nq;          // real query rows
+    int32_t         nq;          // real query rows (single query)
     const int32_t*  db_counts;   // stored row counts; pair p is slot slot_begin + p
     uint32_t        slot_begin;
     void*           scores;      // lcm_score per pair
     int32_t         ratio, dist_floor;
+    // batch (n_batch > 0): pair p belongs to the query b with bat_pair[b] <= p < bat_pair[b + 1], has bat_nq[b] query
+    // rows and is stored slot p - bat_pair[b]
+    uint32_t        n_batch;
+    uint32_t        bat_pair[MAX_QUERY_BATCH + 1];
+    int32_t         bat_nq[MAX_QUERY_BATCH];
 };
 hipError_t launch_finalize(const FinalizeArgs& a, uint32_t n_pairs, hipStream_t st);
 

@@ -169,12 +169,19 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
         it = a.items[blockIdx.x];
         nq = a.q_counts[it.q_frame];
     } else {                                   // implicit item, derived from blockIdx (see ScoreArgs)
-        const uint32_t c = blockIdx.x % a.imp_chunks, g = blockIdx.x / a.imp_chunks;
-        it.q_frame = c;
+        uint32_t b = blockIdx.x, qi = 0, total = a.imp_total, pair0 = 0;
+        int rows = a.imp_nq;
+        if (a.imp_nbatch) {                    // micro-batch: which query does this workgroup belong to (<= 16: scan)
+            while (qi + 1 < a.imp_nbatch && b >= a.bat_wg[qi + 1]) ++qi;
+            b -= a.bat_wg[qi];
+            total = a.bat_elig[qi]; pair0 = a.bat_pair[qi]; rows = a.bat_nq[qi];
+        }
+        const uint32_t c = b % a.imp_chunks, g = b / a.imp_chunks;
+        it.q_frame = qi * a.imp_chunks + c;
         it.slot_begin = g * a.imp_spi;
-        it.n_slots = min(a.imp_spi, a.imp_total - it.slot_begin);
-        it.out_offset = it.slot_begin * a.imp_chunks + c;
-        nq = min((int)a.imp_chunk_rows, a.imp_nq - (int)(c * a.imp_chunk_rows));
+        it.n_slots = min(a.imp_spi, total - it.slot_begin);
+        it.out_offset = (pair0 + it.slot_begin) * a.imp_chunks + c;
+        nq = min((int)a.imp_chunk_rows, rows - (int)(c * a.imp_chunk_rows));
     }
 
     // ---- load this lane's query rows: row = j*THREADS + tid (consecutive lanes -> consecutive 32-byte rows)
@@ -502,20 +509,28 @@ __global__ __launch_bounds__(256) void k_finalize_pairs(FinalizeArgs a) {
     const uint32_t pair = blockIdx.x;
     if (tid == 0) { red_min = 0xFFFFFFFFu; red_sum = 0u; }
     __syncthreads();
+    int nq = a.nq;
+    uint32_t slot = a.slot_begin + pair;
+    if (a.n_batch) {
+        uint32_t b = 0;
+        while (b + 1 < a.n_batch && pair >= a.bat_pair[b + 1]) ++b;
+        nq = a.bat_nq[b];
+        slot = pair - a.bat_pair[b];
+    }
     const uint32_t* d = a.dist + (size_t)pair * a.padded_rows;
     uint32_t dmin = 0xFFFFFFFFu;
-    for (int r = tid; r < a.nq; r += 256) dmin = min(dmin, d[r]);
+    for (int r = tid; r < nq; r += 256) dmin = min(dmin, d[r]);
     atomicMin(&red_min, dmin);
     __syncthreads();
     dmin = red_min;
     const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
     uint32_t cnt = 0;
-    for (int r = tid; r < a.nq; r += 256) cnt += d[r] <= thr ? 1u : 0u;
+    for (int r = tid; r < nq; r += 256) cnt += d[r] <= thr ? 1u : 0u;
     atomicAdd(&red_sum, cnt);
     __syncthreads();
     if (tid == 0) {
-        const int nt = a.db_counts[a.slot_begin + pair];
-        const bool empty = (a.nq <= 0) || (nt <= 0);
+        const int nt = a.db_counts[slot];
+        const bool empty = (nq <= 0) || (nt <= 0);
         uint2 rec;
         rec.x = empty ? 0u : red_sum;
         rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);

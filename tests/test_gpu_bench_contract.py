@@ -60,3 +60,17 @@ def test_two_rank_rehearsal_gloo():
     assert d["config"]["pairs_per_step"] == (150 - 30) * (150 - 29) // 2       # both shards together = the whole search
     assert d["value"] > 0
     assert d["merged_shards_vs_oracle_sample_mismatches"] == 0      # gathered + merged records are right BY VALUE
+
+
+def test_stream_mode_contract():
+    """--mode stream (configs[4] shape) must carry roofline and cpu_baseline too, and its records must equal the oracle's."""
+    r = subprocess.run([sys.executable, "bench.py", "--mode", "stream", "--frames", "150", "--desc", "600", "--steps", "1",
+                        "--warmup", "1", "--cpu-seconds", "1", "--stream-batch", "8"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert REQUIRED <= set(d)
+    assert d["config"]["stream_batch"] == 8 and d["config"]["pairs_per_step"] == (150 - 30) * (150 - 29) // 2
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["launches"] >= 150 // 8 and d["roofline_valu"]["achieved"] > 0 and 0 < d["device_busy_frac"] <= 1.0
+    assert d["cpu_baseline"]["gpu_vs_cpu_sample_mismatches"] == 0 and d["cpu_baseline"]["kind"] == "port"

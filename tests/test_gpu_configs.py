@@ -139,27 +139,37 @@ def test_cfg3_rank_slice_of_the_sharded_search(pkg, oracle):
 
 def test_cfg5_rank_slice_streaming(pkg, oracle):
     """configs[4]: 20000 frames x 2000 descriptors streamed over 8 GPUs.  Rank 5's share of the online run: EVERY frame
-    arrives as host rows and is scored against the rank's device database (pinned staging, async upload / kernel /
-    download, up to 4 queries in flight); frames at positions 5, 13, 21, ... are then appended (pinned ring +
-    hipMemcpyAsync on the copy stream).  24,922,560 pairs in all."""
+    arrives as host rows and is scored against the rank's device database in micro-batches of 8 frames
+    (lcm_query_submit_batch: pinned staging, one upload / launch / download per batch, up to 3 batches in flight); frames
+    at positions 5, 13, 21, ... are then appended (pinned ring + hipMemcpyAsync on the copy stream).  24,922,560 pairs in all."""
     rank, world = 5, 8
     n_frames = 20000
     fs = pkg.synth.make_frames(n_frames, 2000, seed=pkg.synth.BASE_SEED + 5)
     p = pkg.default_params()
     p.min_gap = GAP
     out = []
+    B = 8                                                        # micro-batch: 8 frames per launch (8 ids < min_gap 30)
     with pkg.Matcher(p) as m:
         m.reserve(n_frames // world + 1, fs.stride_rows)
         pending = []
-        for f in range(n_frames):
-            pending.append(m.query_submit(fs.frame(f), int(fs.ids[f])))
-            if f % world == rank:
-                m.append(int(fs.ids[f]), fs.frame(f))
+
+        def take(t):
+            scores, offs = m.query_collect_batch(t, cap=B * 2500)
+            out.extend(scores[int(offs[k]): int(offs[k + 1])] for k in range(len(offs) - 1))
+
+        for f0 in range(0, n_frames, B):
+            fr = range(f0, f0 + B)
+            pending.append(m.query_submit_batch([fs.frame(f) for f in fr], [int(fs.ids[f]) for f in fr]))
+            for f in fr:
+                if f % world == rank:
+                    m.append(int(fs.ids[f]), fs.frame(f))
             if len(pending) == 3:
-                out.append(m.query_collect(pending.pop(0))[0])
+                take(pending.pop(0))
         for t in pending:
-            out.append(m.query_collect(t)[0])
+            take(t)
         assert len(m) == 2500
+        st = m.online_stats()
+        assert st.queries == n_frames and st.pairs == 24922560 and st.distances == 24922560 * 2000 * 2000 and st.kernel_ms > 0
     er = pkg.sharding.shard_eligible_counts(fs.ids, GAP, rank, world)
     assert [len(x) for x in out] == er.tolist()
     offs = pkg.sharding.offsets_from_counts(er)

@@ -445,3 +445,36 @@ def test_argmin_kernel_index_checksum(matcher, oracle, pkg, n_frames, max_desc, 
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+@pytest.mark.parametrize("max_desc,n_frames,batch", [(700, 90, 8), (2000, 40, 16), (300, 60, 5), (1300, 50, 3)])
+def test_micro_batched_online_queries_equal_one_by_one(matcher, oracle, pkg, max_desc, n_frames, batch):
+    """lcm_query_submit_batch: B frames scored by one launch (split and unsplit regimes, ragged frames, an empty frame,
+    queries with different eligibility) == the records of B single submissions == the batch oracle."""
+    fs = pkg.synth.make_frames(n_frames, max_desc, seed=88 + batch, ragged=True, dup_frac=0.3)
+    fs.counts[11] = 0
+    gap = batch                                                   # the exactness condition: id span of a batch <= gap
+    matcher.set_params(min_gap=gap)
+    try:
+        matcher.clear()
+        got = []
+        for f0 in range(0, n_frames, batch):
+            fr = list(range(f0, min(f0 + batch, n_frames)))
+            t = matcher.query_submit_batch([fs.frame(f) for f in fr], [int(fs.ids[f]) for f in fr])
+            with pytest.raises(pkg.LcmError):
+                matcher.query_collect(t)                          # a batch ticket is not a single-query ticket
+            scores, offs = matcher.query_collect_batch(t)
+            assert len(offs) == len(fr) + 1 and int(offs[-1]) == len(scores)
+            for k, f in enumerate(fr):
+                part = scores[int(offs[k]): int(offs[k + 1])]
+                e = sum(1 for i in range(f0) if fs.ids[f] - fs.ids[i] >= gap)
+                assert len(part) == e, (f, len(part), e)
+                got.append((f, part.copy()))
+            for f in fr:
+                matcher.append(int(fs.ids[f]), fs.frame(f))
+        want, woffs = fast_all_vs_all(oracle, fs, oracle.default_params(min_gap=gap))
+        for f, part in got:                                       # the empty frame 11 yields "empty pair" records too
+            np.testing.assert_array_equal(part, want[int(woffs[f]): int(woffs[f + 1])])
+    finally:
+        matcher.set_params(min_gap=30)
+        matcher.clear()
