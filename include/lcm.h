@@ -167,6 +167,17 @@ LCM_API int  lcm_match_features(lcm_handle* h, const uint8_t* query, int nq, con
 LCM_API int  lcm_match_stored(lcm_handle* h, int query_frame_id, int train_frame_id,
                               lcm_dmatch* out, int cap, int* n_out, int* min_dist);
 
+/* The same for MANY pairs in ONE launch (the match lists of all loop candidates of a frame): every pair is cut into
+ * (query chunk x train segment) work items of one kernel launch, a second kernel folds the segments, one download.
+ * out (host) receives the DMatch lists back to back; offsets[n_pairs + 1] (host, required) their bounds; min_dists
+ * (host, optional) each pair's minimum distance, -1 if it has no matches.  A pair with an empty side has no matches. */
+typedef struct lcm_pair_ref { int32_t query_frame_id, train_frame_id; } lcm_pair_ref;
+LCM_API int  lcm_match_stored_batch(lcm_handle* h, const lcm_pair_ref* pairs, int n_pairs,
+                                    lcm_dmatch* out, size_t cap, size_t* offsets, int32_t* min_dists);
+/* ... and one query frame given by the host (the current frame, not stored yet) against n_trains stored frames. */
+LCM_API int  lcm_match_query_batch(lcm_handle* h, const uint8_t* query, int nq, const int32_t* train_frame_ids, int n_trains,
+                                   lcm_dmatch* out, size_t cap, size_t* offsets, int32_t* min_dists);
+
 /* ---- loop search against the stored database --------------------------------------------------------- */
 /* Score `query` (id query_frame_id) against every stored frame with query_frame_id - id >= min_gap, ascending
  * slot order.  out_scores / out_frame_ids need room for lcm_db_size() records. */

@@ -31,6 +31,10 @@ LCM_API int  lcs_match_features(lcs_system* s, int frame1_id, int frame2_id, lcm
 LCM_API int  lcs_detect_loops(lcs_system* s, int current_frame_id, lcm_loop_candidate* out, int cap, int* n_out);
 /* matches between the previous and the current frame computed by the last lcs_process_frame (README.md:96-97) */
 LCM_API int  lcs_get_consecutive_matches(const lcs_system* s, lcm_dmatch* out, int cap, int* n_out);
+/* matchLoopClosures(current_frame_id): DMatch lists of every loop closure recorded for that frame, one launch
+ * (README.md:101 "Re-match features on identified loop frames"); lists back to back in `out`, bounds in offsets. */
+LCM_API int  lcs_match_loop_closures(lcs_system* s, int current_frame_id, lcm_dmatch* out, size_t cap, size_t* offsets,
+                                     int offsets_cap, int* n_lists);
 LCM_API int  lcs_num_frames(const lcs_system* s);                       /* getFrames().size()        hpp:60 */
 LCM_API int  lcs_num_loop_closures(const lcs_system* s);                /* getLoopClosures().size()  hpp:63 */
 LCM_API int  lcs_get_loop_closures(const lcs_system* s, lcm_loop_candidate* out, int cap, int* n_out);

@@ -97,6 +97,8 @@ _SIGNATURES = {
     "lcm_match_pair": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _i32p]),
     "lcm_match_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _i32p, _i32p]),
     "lcm_match_stored": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _i32p, _i32p]),
+    "lcm_match_stored_batch": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, _vp, _vp]),
+    "lcm_match_query_batch": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_size_t, _vp, _vp]),
     "lcm_query_scores": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _i32p]),
     "lcm_query_submit": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i32p]),
     "lcm_query_collect": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i32p]),
@@ -295,6 +297,31 @@ class Matcher:
         _check(self._lib.lcm_match_stored(self._h, query_frame_id, train_frame_id, out.ctypes.data_as(_vp), cap,
                                           C.byref(n), C.byref(m)))
         return out[: n.value], m.value
+
+    def match_stored_batch(self, pairs: Sequence[Tuple[int, int]], cap: Optional[int] = None):
+        """matchFeatures for many stored (query id, train id) pairs in one launch: (list of DMatch arrays, min_dists)."""
+        pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        n = pr.shape[0]
+        cap = 2048 * max(n, 1) if cap is None else cap
+        out = np.zeros(max(cap, 1), DMATCH_DTYPE)
+        offs = np.zeros(n + 1, np.uintp)
+        md = np.zeros(max(n, 1), np.int32)
+        _check(self._lib.lcm_match_stored_batch(self._h, _ptr(pr), n, out.ctypes.data_as(_vp), cap,
+                                                offs.ctypes.data_as(_vp), md.ctypes.data_as(_vp)))
+        return [out[int(offs[i]): int(offs[i + 1])] for i in range(n)], md[:n]
+
+    def match_query_batch(self, query, train_ids: Sequence[int], cap: Optional[int] = None):
+        """One host query frame against many stored frames in one launch: (list of DMatch arrays, min_dists)."""
+        q = _rows(query)
+        ids = np.ascontiguousarray(train_ids, np.int32)
+        n = ids.shape[0]
+        cap = max(q.shape[0], 1) * max(n, 1) if cap is None else cap
+        out = np.zeros(max(cap, 1), DMATCH_DTYPE)
+        offs = np.zeros(n + 1, np.uintp)
+        md = np.zeros(max(n, 1), np.int32)
+        _check(self._lib.lcm_match_query_batch(self._h, _ptr(q), q.shape[0], _ptr(ids), n, out.ctypes.data_as(_vp), cap,
+                                               offs.ctypes.data_as(_vp), md.ctypes.data_as(_vp)))
+        return [out[int(offs[i]): int(offs[i + 1])] for i in range(n)], md[:n]
 
     # -- loop search -------------------------------------------------------------------------------
     def query_scores(self, query, query_frame_id: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -584,6 +611,7 @@ _HOST_SIGNATURES = {
     "lcs_match_features": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
     "lcs_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i32p]),
     "lcs_get_consecutive_matches": (C.c_int, [_vp, _vp, C.c_int, _i32p]),
+    "lcs_match_loop_closures": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_int, _i32p]),
     "lcs_num_frames": (C.c_int, [_vp]),
     "lcs_num_loop_closures": (C.c_int, [_vp]),
     "lcs_get_loop_closures": (C.c_int, [_vp, _vp, C.c_int, _i32p]),
@@ -648,6 +676,14 @@ class LoopClosingSystem:
         n = C.c_int32(0)
         self._hcheck(self._lib.lcs_get_consecutive_matches(self._s, out.ctypes.data_as(_vp), cap, C.byref(n)))
         return out[: n.value]
+
+    def matchLoopClosures(self, current_frame_id: int, cap: int = 1 << 20):
+        out = np.zeros(cap, DMATCH_DTYPE)
+        offs = np.zeros(4096, np.uintp)
+        n = C.c_int32(0)
+        self._hcheck(self._lib.lcs_match_loop_closures(self._s, current_frame_id, out.ctypes.data_as(_vp), cap,
+                                                       offs.ctypes.data_as(_vp), len(offs), C.byref(n)))
+        return [out[int(offs[i]): int(offs[i + 1])] for i in range(n.value)]
 
     def numFrames(self) -> int:
         return self._lib.lcs_num_frames(self._s)

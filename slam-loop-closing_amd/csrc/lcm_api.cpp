@@ -136,28 +136,6 @@ int launch_and_time(lcm_handle* h, const lcm::ScoreArgs& a, uint32_t n_items, in
     return LCM_OK;
 }
 
-// Upload host rows into a scratch device buffer as `n_chunks` pseudo-frames of `chunk_rows` rows.
-int upload_rows(lcm_handle* h, uint8_t*& d_buf, size_t& d_bytes, const uint8_t* rows, int n, int stride_rows_total,
-                bool pad_last) {
-    size_t need = (size_t)stride_rows_total * LCM_DESC_BYTES;
-    {
-        size_t have = d_bytes;
-        uint8_t* p = d_buf;
-        int rc = ensure_dev(p, have, need, ARENA_SLACK);
-        d_buf = p; d_bytes = have;
-        if (rc) return rc;
-    }
-    if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(d_buf, rows, (size_t)n * LCM_DESC_BYTES, hipMemcpyHostToDevice, h->stream));
-        if (pad_last) {
-            for (int r = n; r < padded_rows(n); ++r)
-                HIP_TRY(hipMemcpyAsync(d_buf + (size_t)r * LCM_DESC_BYTES, rows + (size_t)(n - 1) * LCM_DESC_BYTES,
-                                       LCM_DESC_BYTES, hipMemcpyHostToDevice, h->stream));
-        }
-    }
-    return LCM_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -222,8 +200,7 @@ void lcm_destroy(lcm_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     (void)hipFree(h->d_rows); (void)hipFree(h->d_counts);
-    (void)hipFree(h->d_qbuf); (void)hipFree(h->d_qcounts); (void)hipFree(h->d_tbuf); (void)hipFree(h->d_tcounts);
-    (void)hipFree(h->d_keys); (void)hipFree(h->d_scores); (void)hipFree(h->d_items); (void)hipFree(h->plan.d_items);
+    (void)hipFree(h->d_keys); (void)hipFree(h->plan.d_items);
     (void)hipFree(h->d_bulk_scores); (void)hipFree(h->d_meta); (void)hipFree(h->d_cands);
     for (QuerySlot& q : h->qslots) {
         (void)hipFree(q.d_query); (void)hipFree(q.d_scores); (void)hipFree(q.d_dist);
@@ -238,6 +215,9 @@ void lcm_destroy(lcm_handle* h) {
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
     }
     if (h->h_counts) (void)hipHostFree(h->h_counts);
+    if (h->h_pair_stage) (void)hipHostFree(h->h_pair_stage);
+    if (h->h_final_keys) (void)hipHostFree(h->h_final_keys);
+    (void)hipFree(h->d_pair_stage);
     if (h->db_ready) (void)hipEventDestroy(h->db_ready);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -456,66 +436,129 @@ struct RowSrc {
     int n;
 };
 
-// Best packed key (dist << 22 | GLOBAL train index) of every query row against all train rows -> keys_out[0..nq).
+// One matchFeatures job of a batch: query rows x train rows, both given as ROW INDICES into one query matrix and one
+// train matrix on the device (the database arena, or this call's staging block).
+struct PairJob { uint32_t q_row; int nq; uint32_t t_row; int nt; };
+
+// Best packed key (dist << 22 | GLOBAL train index) of every query row of every job -> keys (pinned host memory owned
+// by the handle; job p's rows start at row0[p]).
 //
-// One pair is cut into (query chunk of <= 2048 rows) x (train segment of SEG rows) work items so that a single
-// 2000 x 2000 match occupies ~60 workgroups instead of one (N2: consecutive-frame matching latency).  Each item is an
-// ordinary "query frame vs one stored frame" unit of the scoring kernel: the train matrix is addressed as pseudo-frames
-// of SEG rows.  Per-segment keys carry segment-local indices; the host folds them with the segment base, and because
-// the fold is a min over (dist, global index) keys the FIRST minimum still wins.
+// Every pair is cut into (query chunk of <= 2048 rows) x (train segment of SEG rows) work items (PairItem) so that
+// a single 2000 x 2000 match occupies ~64 workgroups instead of one and a batch of loop candidates fills the chip:
+// ONE launch of the key kernel over all items of all pairs, ONE launch of k_fold_pair_keys (per-segment keys carry
+// segment-local train indices; the fold adds the segment base and takes the min, so the FIRST minimum wins across
+// segments), ONE download.  `stage_bytes` bytes at h->h_pair_stage (already filled by the caller with any host rows)
+// precede the items / descriptors this function appends, and the whole block goes up in ONE hipMemcpyAsync.
+static int run_pair_jobs(lcm_handle* h, const uint8_t* d_q_base, const uint8_t* d_t_base, bool q_in_stage, bool t_in_stage,
+                         size_t stage_bytes, const std::vector<PairJob>& jobs, const uint32_t** keys_out, std::vector<size_t>& row0) {
+    const int CH = lcm::MAX_FUSED_QUERY_ROWS;
+    const size_t P = jobs.size();
+    row0.assign(P + 1, 0);
+    size_t n_items = 0, total_rows = 0;
+    int max_nq = 0;
+    size_t chunks_total = 0;
+    for (const PairJob& jb : jobs) chunks_total += (size_t)((jb.nq + CH - 1) / CH);
+    // aim at ~1536 workgroups over the whole batch (6 per CU); a segment is at least 32 rows, a multiple of 16
+    const int seg_target = (int)std::max<size_t>(1, 1536 / std::max<size_t>(chunks_total, 1));
+    std::vector<lcm::PairItem> items;
+    std::vector<lcm::PairDesc> descs(P);
+    for (size_t p = 0; p < P; ++p) {
+        const PairJob& jb = jobs[p];
+        if (jb.nt > LCM_MAX_TRAIN_ROWS) return fail(LCM_ERR_CAPACITY, "at most %d train rows per matrix", LCM_MAX_TRAIN_ROWS);
+        const int n_chunks = (jb.nq + CH - 1) / CH;
+        int n_seg = std::max(1, std::min((jb.nt + 31) / 32, seg_target));
+        const int SEG = round_up((jb.nt + n_seg - 1) / n_seg, 16);
+        n_seg = std::max(1, (jb.nt + SEG - 1) / SEG);
+        if (SEG >= (1 << 20)) return fail(LCM_ERR_CAPACITY, "train segment of %d rows", SEG);
+        descs[p] = {(uint32_t)items.size(), (uint32_t)n_seg, (uint32_t)SEG, (uint32_t)jb.nq, (uint32_t)total_rows};
+        for (int c = 0; c < n_chunks; ++c)
+            for (int g = 0; g < n_seg; ++g) {
+                const uint32_t nqc = (uint32_t)std::min(CH, jb.nq - c * CH), ntg = (uint32_t)std::min(SEG, jb.nt - g * SEG);
+                items.push_back({jb.q_row + (uint32_t)(c * CH), jb.t_row + (uint32_t)(g * SEG), nqc | (ntg << 12), (uint32_t)items.size()});
+            }
+        row0[p] = total_rows;
+        total_rows += (size_t)jb.nq;
+        max_nq = std::max(max_nq, jb.nq);
+    }
+    row0[P] = total_rows;
+    n_items = items.size();
+    *keys_out = nullptr;
+    if (n_items == 0 || total_rows == 0) return LCM_OK;
+
+    // ---- one staging block up: [caller's rows | items | descriptors]
+    const size_t off_items = (stage_bytes + 255) & ~(size_t)255;
+    const size_t off_descs = off_items + sizeof(lcm::PairItem) * n_items;
+    const size_t up_bytes = off_descs + sizeof(lcm::PairDesc) * P;
+    int rc = LCM_OK;
+    if (up_bytes > h->h_pair_stage_bytes) {           // grow, keeping the rows the caller has already staged
+        uint8_t* bigger = nullptr;
+        const size_t want = up_bytes + up_bytes / 2;
+        HIP_TRY(hipHostMalloc((void**)&bigger, want, hipHostMallocDefault));
+        if (h->h_pair_stage) { memcpy(bigger, h->h_pair_stage, std::min(stage_bytes, h->h_pair_stage_bytes)); HIP_TRY(hipHostFree(h->h_pair_stage)); }
+        h->h_pair_stage = bigger; h->h_pair_stage_bytes = want;
+    }
+    rc = ensure_dev(h->d_pair_stage, h->d_pair_stage_bytes, up_bytes, ARENA_SLACK); if (rc) return rc;
+    memcpy(h->h_pair_stage + off_items, items.data(), sizeof(lcm::PairItem) * n_items);
+    memcpy(h->h_pair_stage + off_descs, descs.data(), sizeof(lcm::PairDesc) * P);
+    rc = ensure_dev(h->d_keys, h->d_keys_n, n_items * (size_t)CH + total_rows); if (rc) return rc;
+    rc = ensure_pinned(h->h_final_keys, h->h_final_keys_n, total_rows); if (rc) return rc;
+    // only the part the caller did not fill needs the copy when the rows are device-resident already
+    const size_t up_from = (q_in_stage || t_in_stage) ? 0 : off_items;
+    HIP_TRY(hipMemcpyAsync(h->d_pair_stage + up_from, h->h_pair_stage + up_from, up_bytes - up_from, hipMemcpyHostToDevice, h->stream));
+
+    lcm::ScoreArgs a{};
+    a.q_rows = (const uint32_t*)(q_in_stage ? h->d_pair_stage : d_q_base);
+    a.db_rows = (const uint32_t*)(t_in_stage ? h->d_pair_stage : d_t_base);
+    a.pair_items = reinterpret_cast<const lcm::PairItem*>(h->d_pair_stage + off_items);
+    a.scores = nullptr; a.keys = h->d_keys; a.keys_stride = CH;
+    a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
+    rc = launch_and_time(h, a, (uint32_t)n_items, max_nq > CH ? CH : max_nq, true); if (rc) return rc;
+    lcm::FoldArgs f{};
+    f.seg_keys = h->d_keys;
+    f.pairs = reinterpret_cast<const lcm::PairDesc*>(h->d_pair_stage + off_descs);
+    f.final_keys = h->d_keys + n_items * (size_t)CH;
+    f.n_pairs = (uint32_t)P;
+    hipError_t e = lcm::launch_fold_pair_keys(f, (uint32_t)max_nq, h->stream);
+    if (e != hipSuccess) return fail(LCM_ERR_HIP, "fold kernel launch failed: %s", hipGetErrorString(e));
+    h->info.launches = 2;
+    h->info.pairs = P; h->info.distances = 0; h->info.algo_bytes = 0;
+    for (const PairJob& jb : jobs) {
+        h->info.distances += (uint64_t)jb.nq * (uint64_t)jb.nt;
+        h->info.algo_bytes += (uint64_t)jb.nt * 32 + (uint64_t)jb.nq * 32 + 8;
+    }
+    HIP_TRY(hipMemcpyAsync(h->h_final_keys, f.final_keys, sizeof(uint32_t) * total_rows, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *keys_out = h->h_final_keys;
+    return LCM_OK;
+}
+
+// One pair with rows from the host and / or the device: host rows travel inside the staging block (the train matrix with
+// its padding rows — copies of the last row — written straight into pinned memory: no extra copies).
 static int pair_keys(lcm_handle* h, RowSrc q, RowSrc t, std::vector<uint32_t>& keys_out) {
     int rc = set_device(h); if (rc) return rc;
-    const int nq = q.n, nt = t.n;
-    if (nt > LCM_MAX_TRAIN_ROWS) return fail(LCM_ERR_CAPACITY, "at most %d train rows per call", LCM_MAX_TRAIN_ROWS);
-    const int CH = lcm::MAX_FUSED_QUERY_ROWS;
-    const int n_chunks = (nq + CH - 1) / CH;
-    int n_seg = std::max(1, std::min((nt + 31) / 32, std::max(1, 512 / n_chunks)));
-    const int SEG = round_up((nt + n_seg - 1) / n_seg, ROW_PAD);
-    n_seg = (nt + SEG - 1) / SEG;
-    const uint8_t* d_q = q.dev;
-    const uint8_t* d_t = t.dev;
-    if (!d_q) { rc = upload_rows(h, h->d_qbuf, h->d_qbuf_bytes, q.host, nq, n_chunks * CH, false); if (rc) return rc; d_q = h->d_qbuf; }
-    if (!d_t) { rc = upload_rows(h, h->d_tbuf, h->d_tbuf_bytes, t.host, nt, padded_rows(nt) + ROW_PAD, true); if (rc) return rc; d_t = h->d_tbuf; }
-    else { rc = wait_db(h); if (rc) return rc; }
-    if (q.dev) { rc = wait_db(h); if (rc) return rc; }
-    const size_t n_items = (size_t)n_chunks * n_seg;
-    std::vector<int32_t> qc(n_chunks), tc(n_seg);
-    std::vector<lcm::WorkItem> items(n_items);
-    for (int g = 0; g < n_seg; ++g) tc[g] = std::min(SEG, nt - g * SEG);
-    for (int c = 0; c < n_chunks; ++c) {
-        qc[c] = std::min(CH, nq - c * CH);
-        for (int g = 0; g < n_seg; ++g) items[(size_t)c * n_seg + g] = {(uint32_t)c, (uint32_t)g, 1u, (uint32_t)(c * n_seg + g)};
-    }
-    rc = ensure_dev(h->d_qcounts, h->d_qcounts_n, (size_t)n_chunks); if (rc) return rc;
-    rc = ensure_dev(h->d_tcounts, h->d_tcounts_n, (size_t)n_seg); if (rc) return rc;
-    rc = ensure_dev(h->d_items, h->d_items_n, n_items); if (rc) return rc;
-    rc = ensure_dev(h->d_keys, h->d_keys_n, n_items * CH); if (rc) return rc;
-    rc = ensure_dev(h->d_scores, h->d_scores_n, n_items); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h->d_qcounts, qc.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_tcounts, tc.data(), sizeof(int32_t) * n_seg, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_items, items.data(), sizeof(lcm::WorkItem) * n_items, hipMemcpyHostToDevice, h->stream));
-    lcm::ScoreArgs a{};
-    a.q_rows = (const uint32_t*)d_q; a.q_counts = h->d_qcounts; a.q_stride_words = CH * LCM_DESC_WORDS;
-    a.db_rows = (const uint32_t*)d_t; a.db_counts = h->d_tcounts; a.db_stride_words = (uint32_t)SEG * LCM_DESC_WORDS;
-    a.items = h->d_items; a.scores = h->d_scores; a.keys = h->d_keys; a.keys_stride = CH;
-    a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
-    const int max_rows = n_chunks > 1 ? CH : nq;
-    rc = launch_and_time(h, a, (uint32_t)n_items, max_rows, true); if (rc) return rc;
-    h->info.pairs = 1; h->info.distances = (uint64_t)nq * nt;
-    h->info.algo_bytes = (uint64_t)nt * 32 + (uint64_t)nq * 32 + 8;
-    std::vector<uint32_t>& raw = h->h_keys;
-    raw.resize(n_items * CH);
-    HIP_TRY(hipMemcpyAsync(raw.data(), h->d_keys, sizeof(uint32_t) * raw.size(), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    // fold the segments (integer bookkeeping on shipped keys; no distance is computed on the host)
-    keys_out.assign((size_t)nq, 0xFFFFFFFFu);
-    for (int c = 0; c < n_chunks; ++c)
-        for (int g = 0; g < n_seg; ++g) {
-            const uint32_t* src = raw.data() + ((size_t)c * n_seg + g) * CH;
-            uint32_t* dst = keys_out.data() + (size_t)c * CH;
-            const uint32_t base = (uint32_t)g * SEG;
-            for (int i = 0; i < qc[c]; ++i) dst[i] = std::min(dst[i], src[i] + base);
+    const size_t q_bytes = q.dev ? 0 : (size_t)q.n * LCM_DESC_BYTES;
+    const size_t t_off = (q_bytes + 255) & ~(size_t)255;
+    const size_t t_bytes = t.dev ? 0 : (size_t)(padded_rows(t.n) + ROW_PAD) * LCM_DESC_BYTES;
+    const size_t stage_bytes = t_off + t_bytes;
+    if (stage_bytes) {
+        rc = ensure_pinned(h->h_pair_stage, h->h_pair_stage_bytes, stage_bytes + 65536); if (rc) return rc;
+        if (!q.dev && q.n > 0) memcpy(h->h_pair_stage, q.host, q_bytes);
+        if (!t.dev && t.n > 0) {
+            uint8_t* dst = h->h_pair_stage + t_off;
+            memcpy(dst, t.host, (size_t)t.n * LCM_DESC_BYTES);
+            for (int r = t.n; r < padded_rows(t.n) + ROW_PAD; ++r) memcpy(dst + (size_t)r * LCM_DESC_BYTES, t.host + (size_t)(t.n - 1) * LCM_DESC_BYTES, LCM_DESC_BYTES);
         }
+    }
+    if (q.dev || t.dev) { rc = wait_db(h); if (rc) return rc; }
+    // device-resident sides are addressed from the arena base (row index = byte offset / 32)
+    std::vector<PairJob> jobs(1);
+    jobs[0].nq = q.n; jobs[0].nt = t.n;
+    jobs[0].q_row = q.dev ? (uint32_t)((size_t)(q.dev - h->d_rows) / LCM_DESC_BYTES) : 0u;
+    jobs[0].t_row = t.dev ? (uint32_t)((size_t)(t.dev - h->d_rows) / LCM_DESC_BYTES) : (uint32_t)(t_off / LCM_DESC_BYTES);
+    const uint32_t* keys = nullptr;
+    std::vector<size_t> row0;
+    rc = run_pair_jobs(h, h->d_rows, h->d_rows, !q.dev, !t.dev, stage_bytes, jobs, &keys, row0); if (rc) return rc;
+    keys_out.assign(keys, keys + q.n);
     return LCM_OK;
 }
 
@@ -593,6 +636,71 @@ static int match_stored_impl(lcm_handle* h, int query_frame_id, int train_frame_
     std::vector<uint32_t> keys;
     rc = pair_keys(h, q, t, keys); if (rc) return rc;
     return filter_keys(h, keys, q.n, out, n_out, min_dist);
+}
+
+// Keys of one job -> its DMatch list appended at out[*n_total ...] (README.md:117 filter, query order kept).
+static int emit_matches(const lcm_handle* h, const uint32_t* keys, int nq, lcm_dmatch* out, size_t cap, size_t* n_total, int32_t* min_dist) {
+    uint32_t m = 0xFFFFFFFFu;
+    for (int i = 0; i < nq; ++i) m = std::min(m, keys[i] >> lcm::KEY_SHIFT);
+    const uint32_t thr = std::max((uint32_t)h->params.ratio * m, (uint32_t)h->params.dist_floor);
+    size_t k = *n_total;
+    for (int i = 0; i < nq; ++i) {
+        const uint32_t d = keys[i] >> lcm::KEY_SHIFT;
+        if (d <= thr) {
+            if (k >= cap) return fail(LCM_ERR_CAPACITY, "match buffer holds %zu records: too small", cap);
+            out[k].query_idx = i;
+            out[k].train_idx = (int32_t)(keys[i] & lcm::KEY_IDX_MASK);
+            out[k].img_idx = 0;
+            out[k].distance = (float)d;
+            ++k;
+        }
+    }
+    *n_total = k;
+    if (min_dist) *min_dist = nq > 0 ? (int32_t)m : -1;
+    return LCM_OK;
+}
+
+// matchFeatures for MANY pairs in one launch (N1: the match lists of all loop candidates of a frame, README.md:101).
+// q_host != NULL: one query frame from the host against stored train frames; else both sides stored.
+static int match_batch_impl(lcm_handle* h, const uint8_t* q_host, int nq_host, const lcm_pair_ref* pairs, const int32_t* train_ids,
+                            int n_pairs, lcm_dmatch* out, size_t cap, size_t* offsets, int32_t* min_dists) {
+    if (!h || n_pairs < 0 || !offsets || (n_pairs > 0 && !pairs && !train_ids)) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    offsets[0] = 0;
+    int rc = set_device(h); if (rc) return rc;
+    if (q_host && nq_host > lcm::MAX_FUSED_QUERY_ROWS * 64) return fail(LCM_ERR_CAPACITY, "query frame too large");
+    std::vector<PairJob> jobs;
+    std::vector<int> job_of((size_t)n_pairs, -1);
+    size_t stage_bytes = 0;
+    if (q_host && nq_host > 0) {
+        stage_bytes = (size_t)nq_host * LCM_DESC_BYTES;
+        rc = ensure_pinned(h->h_pair_stage, h->h_pair_stage_bytes, stage_bytes + 65536 + (size_t)n_pairs * 2048); if (rc) return rc;
+        memcpy(h->h_pair_stage, q_host, stage_bytes);
+    }
+    for (int p = 0; p < n_pairs; ++p) {
+        RowSrc q{}, t{};
+        if (q_host) { q.host = q_host; q.n = nq_host; }
+        else { rc = stored_src(h, pairs[p].query_frame_id, &q, nullptr); if (rc) return rc; }
+        rc = stored_src(h, q_host ? train_ids[p] : pairs[p].train_frame_id, &t, nullptr); if (rc) return rc;
+        if (q.n == 0 || t.n == 0) continue;                     // BFMatcher: an empty side => no matches
+        job_of[(size_t)p] = (int)jobs.size();
+        jobs.push_back({q.dev ? (uint32_t)((size_t)(q.dev - h->d_rows) / LCM_DESC_BYTES) : 0u, q.n,
+                        (uint32_t)((size_t)(t.dev - h->d_rows) / LCM_DESC_BYTES), t.n});
+    }
+    rc = wait_db(h); if (rc) return rc;
+    const uint32_t* keys = nullptr;
+    std::vector<size_t> row0;
+    rc = run_pair_jobs(h, h->d_rows, h->d_rows, q_host != nullptr, false, stage_bytes, jobs, &keys, row0); if (rc) return rc;
+    size_t total = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        offsets[p] = total;
+        if (min_dists) min_dists[p] = -1;
+        const int j = job_of[(size_t)p];
+        if (j < 0) continue;
+        rc = emit_matches(h, keys + row0[(size_t)j], jobs[(size_t)j].nq, out, out ? cap : 0, &total, min_dists ? &min_dists[p] : nullptr);
+        if (rc) return rc;
+    }
+    offsets[n_pairs] = total;
+    return LCM_OK;
 }
 
 /* ---- loop search ------------------------------------------------------------------------------------- */
@@ -1290,6 +1398,14 @@ int lcm_query_submit(lcm_handle* h, const uint8_t* query, int nq, int query_fram
 }
 int lcm_query_collect(lcm_handle* h, int ticket, lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out) {
     return guarded([&] { return query_collect_impl(h, ticket, out_scores, out_frame_ids, cap, n_out); });
+}
+int lcm_match_stored_batch(lcm_handle* h, const lcm_pair_ref* pairs, int n_pairs, lcm_dmatch* out, size_t cap, size_t* offsets, int32_t* min_dists) {
+    return guarded([&] { return match_batch_impl(h, nullptr, 0, pairs, nullptr, n_pairs, out, cap, offsets, min_dists); });
+}
+int lcm_match_query_batch(lcm_handle* h, const uint8_t* query, int nq, const int32_t* train_frame_ids, int n_trains, lcm_dmatch* out, size_t cap, size_t* offsets, int32_t* min_dists) {
+    if (nq < 0 || (nq > 0 && !query)) return fail(LCM_ERR_INVALID_ARG, "bad query rows");
+    static const uint8_t none[LCM_DESC_BYTES] = {0};
+    return guarded([&] { return match_batch_impl(h, query ? query : none, nq, nullptr, train_frame_ids, n_trains, out, cap, offsets, min_dists); });
 }
 int lcm_query_submit_batch(lcm_handle* h, const uint8_t* const* queries, const int* nq, const int* query_frame_ids, int n_queries, int* ticket) {
     return guarded([&] { return query_submit_batch_impl(h, queries, nq, query_frame_ids, n_queries, ticket); });

@@ -121,14 +121,10 @@ struct lcm_handle {
     int stage_next = 0;
 
     // scratch for query uploads / pair mode / results
-    uint8_t* d_qbuf = nullptr;  size_t d_qbuf_bytes = 0;
-    int32_t* d_qcounts = nullptr; size_t d_qcounts_n = 0;
-    uint8_t* d_tbuf = nullptr;  size_t d_tbuf_bytes = 0;
-    int32_t* d_tcounts = nullptr; size_t d_tcounts_n = 0;
     uint32_t* d_keys = nullptr; size_t d_keys_n = 0;
-    lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
-    lcm::WorkItem* d_items = nullptr; size_t d_items_n = 0;
-    std::vector<uint32_t> h_keys;
+    uint8_t* h_pair_stage = nullptr; size_t h_pair_stage_bytes = 0;   // pair mode: pinned [rows | items | descriptors]
+    uint8_t* d_pair_stage = nullptr; size_t d_pair_stage_bytes = 0;
+    uint32_t* h_final_keys = nullptr; size_t h_final_keys_n = 0;      // pair mode: pinned landing zone of the folded keys
     lcm_score* d_bulk_scores = nullptr; size_t d_bulk_scores_n = 0;   // lcm_all_vs_all_loops: scores stay on the device
     size_t bulk_scores_valid = 0;                                     // records of the last fused call still in there
     int32_t* d_meta = nullptr; size_t d_meta_n = 0;

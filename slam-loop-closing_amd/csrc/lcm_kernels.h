@@ -19,6 +19,17 @@ struct WorkItem {
     uint32_t out_offset;
 };
 
+// Pair mode (matchFeatures / match lists): one unit = <= 2048 query rows starting at row q_row of q_rows against nt
+// train rows starting at row t_row of db_rows (a SEGMENT of a train matrix: several items share one pair so that a
+// single 2000 x 2000 match spreads over ~64 workgroups).  t_row and every segment length but a matrix's last are
+// multiples of 4; the last segment ends where the matrix's padding rows (copies of its last row) begin.
+struct PairItem {
+    uint32_t q_row;
+    uint32_t t_row;
+    uint32_t nq_nt;              // nq (12 bits, <= 2048 -> stored as nq) | nt << 12 (20 bits)
+    uint32_t out_offset;         // keys[out_offset * keys_stride + local query row]
+};
+
 struct ScoreArgs {
     const uint32_t* q_rows;      // query frames: frame f at q_rows + f * q_stride_words, rows of 8 dwords
     const int32_t*  q_counts;    // rows per query frame
@@ -27,6 +38,7 @@ struct ScoreArgs {
     const int32_t*  db_counts;
     uint32_t        db_stride_words;
     const WorkItem* items;       // NULL => implicit items (online queries: nothing to upload), see imp_* below
+    const PairItem* pair_items;  // non-NULL => pair mode: overrides items / implicit items; keys must be non-NULL
     void*           scores;      // lcm_score records (8 bytes each)
     uint32_t*       keys;        // optional: best packed key per query row, keys[pair * keys_stride + row]
     uint32_t        keys_stride;
@@ -72,6 +84,24 @@ struct FinalizeArgs {
     int32_t         bat_nq[MAX_QUERY_BATCH];
 };
 hipError_t launch_finalize(const FinalizeArgs& a, uint32_t n_pairs, hipStream_t st);
+
+// Pair mode, second step: fold the per-segment keys of every pair (segment-local train indices) into one key per query
+// row with GLOBAL train indices: final[out_row0 + r] = min over segments g of (seg_keys[item(c, g)][r mod 2048] + g *
+// seg_rows), c = r / 2048.  min over (dist, global index) keys keeps the FIRST minimum across segments.
+struct PairDesc {
+    uint32_t first_item;         // item (c, g) of this pair is first_item + c * n_seg + g
+    uint32_t n_seg;
+    uint32_t seg_rows;
+    uint32_t nq;
+    uint32_t out_row0;           // first row of this pair in the folded key array
+};
+struct FoldArgs {
+    const uint32_t* seg_keys;    // per item: MAX_FUSED_QUERY_ROWS keys
+    const PairDesc* pairs;
+    uint32_t*       final_keys;
+    uint32_t        n_pairs;
+};
+hipError_t launch_fold_pair_keys(const FoldArgs& a, uint32_t max_nq, hipStream_t st);
 
 // On-device loop test over a finished score array (BASELINE.json configs[3] "fused on-device filter + loop test"):
 // pair p belongs to query frame c = upper_bound(offsets, p) - 1 and stored slot p - offsets[c]; a candidate is

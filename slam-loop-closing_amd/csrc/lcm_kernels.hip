@@ -165,9 +165,20 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
 
     WorkItem it;
     int nq;
-    if (a.items) {
+    size_t q_word0;                            // first dword of this item's query rows in q_rows
+    uint32_t pair_t_row = 0;
+    int pair_nt = -1;                          // >= 0: pair mode (one train segment given by the item itself)
+    if (a.pair_items) {
+        const PairItem pi = a.pair_items[blockIdx.x];
+        it.q_frame = 0; it.slot_begin = 0; it.n_slots = 1; it.out_offset = pi.out_offset;
+        nq = (int)(pi.nq_nt & 0xFFFu);
+        pair_nt = (int)(pi.nq_nt >> 12);
+        pair_t_row = pi.t_row;
+        q_word0 = (size_t)pi.q_row * 8;
+    } else if (a.items) {
         it = a.items[blockIdx.x];
         nq = a.q_counts[it.q_frame];
+        q_word0 = (size_t)it.q_frame * a.q_stride_words;
     } else {                                   // implicit item, derived from blockIdx (see ScoreArgs)
         uint32_t b = blockIdx.x, qi = 0, total = a.imp_total, pair0 = 0;
         int rows = a.imp_nq;
@@ -182,13 +193,14 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
         it.n_slots = min(a.imp_spi, total - it.slot_begin);
         it.out_offset = (pair0 + it.slot_begin) * a.imp_chunks + c;
         nq = min((int)a.imp_chunk_rows, rows - (int)(c * a.imp_chunk_rows));
+        q_word0 = (size_t)it.q_frame * a.q_stride_words;
     }
 
     // ---- load this lane's query rows: row = j*THREADS + tid (consecutive lanes -> consecutive 32-byte rows)
     uint32_t q[QPT][8];
     auto valid = [&](int j) { return j * THREADS + tid < nq; };     // recomputed where needed: keeps VGPRs <= 80
     {
-        const uint4* qbase = reinterpret_cast<const uint4*>(a.q_rows + (size_t)it.q_frame * a.q_stride_words);
+        const uint4* qbase = reinterpret_cast<const uint4*>(a.q_rows + q_word0);
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
             const int row = j * THREADS + tid;
@@ -201,8 +213,9 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
 
     for (uint32_t s = 0; s < it.n_slots; ++s) {
         const uint32_t slot = it.slot_begin + s;
-        const int nt = ((siptr_t)a.db_counts)[slot];
-        sptr_t T = (sptr_t)(a.db_rows + (size_t)slot * a.db_stride_words);
+        const int nt = pair_nt >= 0 ? pair_nt : ((siptr_t)a.db_counts)[slot];
+        const uint32_t* Tbase = pair_nt >= 0 ? a.db_rows + (size_t)pair_t_row * 8 : a.db_rows + (size_t)slot * a.db_stride_words;
+        sptr_t T = (sptr_t)Tbase;
 
         uint32_t best[QPT];
 #pragma unroll
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
                 // the last, possibly partial group (a repeat of an already folded group changes nothing) ...
                 fold_group((uint32_t)(nt - 1) / ARGMIN_GROUP);
                 // ... then the re-scan of each query row's winning group for the first row that attains the minimum
-                const uint32_t* Tg = a.db_rows + (size_t)slot * a.db_stride_words;      // wave-uniform frame base
+                const uint32_t* Tg = Tbase;                                              // wave-uniform frame base
                 const uint32_t last_off = (uint32_t)(nt - 1) * 32u;
 #pragma unroll
                 for (int j = 0; j < QPT; ++j) {
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
             uint2 rec;
             rec.x = empty ? 0u : cnt;
             rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
-            reinterpret_cast<uint2*>(a.scores)[out] = rec;
+            if (a.scores) reinterpret_cast<uint2*>(a.scores)[out] = rec;
             if (ARGMIN && a.idx_sums) a.idx_sums[out] = empty ? 0u : red_idx[par];
         }
     }
@@ -538,6 +551,23 @@ __global__ __launch_bounds__(256) void k_finalize_pairs(FinalizeArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_fold_pair_keys(FoldArgs a) {
+    const PairDesc p = a.pairs[blockIdx.y];
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= p.nq) return;
+    const uint32_t c = r / MAX_FUSED_QUERY_ROWS, lr = r % MAX_FUSED_QUERY_ROWS;
+    const uint32_t* src = a.seg_keys + ((size_t)p.first_item + (size_t)c * p.n_seg) * MAX_FUSED_QUERY_ROWS + lr;
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t g = 0; g < p.n_seg; ++g) best = min(best, src[(size_t)g * MAX_FUSED_QUERY_ROWS] + g * p.seg_rows);
+    a.final_keys[p.out_row0 + r] = best;
+}
+
+hipError_t launch_fold_pair_keys(const FoldArgs& a, uint32_t max_nq, hipStream_t st) {
+    if (a.n_pairs == 0 || max_nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fold_pair_keys, dim3((max_nq + 255) / 256, a.n_pairs), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_finalize(const FinalizeArgs& a, uint32_t n_pairs, hipStream_t st) {
     if (n_pairs == 0) return hipSuccess;
     hipLaunchKernelGGL(k_finalize_pairs, dim3(n_pairs), dim3(256), 0, st, a);
@@ -667,7 +697,7 @@ hipError_t launch_merge_shards(const MergeArgs& a, hipStream_t st) {
 // All selectable so they can be measured on the same workload (bench.py --variant N).
 hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
                         hipStream_t st) {
-    if (variant >= 2 && max_query_rows <= 2048 && a.db_stride_words != 0 && a.db_stride_words <= 2048 * 8) {
+    if (variant >= 2 && !a.pair_items && max_query_rows <= 2048 && a.db_stride_words != 0 && a.db_stride_words <= 2048 * 8) {
         if (n_items == 0) return hipSuccess;
         const bool argmin = write_keys || variant == 3;
         if (write_keys) hipLaunchKernelGGL((k_score_trainlane<true, true>), dim3(n_items), dim3(256), 0, st, a);

@@ -94,6 +94,24 @@ std::vector<LoopCandidate> LoopClosingSystem::detectLoops(int current_frame_id) 
     return out;
 }
 
+std::vector<std::vector<DMatch>> LoopClosingSystem::matchLoopClosures(int current_frame_id) {
+    const Frame* cur = findFrame(current_frame_id);
+    if (!cur) throw std::out_of_range("matchLoopClosures: unknown frame id");
+    std::vector<int32_t> trains;
+    for (const LoopCandidate& c : loop_closures_)
+        if (c.current_frame_id == current_frame_id) trains.push_back(c.matched_frame_id);
+    std::vector<std::vector<DMatch>> lists(trains.size());
+    if (trains.empty()) return lists;
+    std::vector<DMatch> flat((size_t)std::max(cur->rows(), 1) * trains.size());
+    std::vector<size_t> offs(trains.size() + 1, 0);
+    static const uint8_t dummy[32] = {0};
+    if (lcm_match_query_batch(matcher_, cur->rows() > 0 ? cur->descriptors.data() : dummy, cur->rows(), trains.data(), (int)trains.size(),
+                              reinterpret_cast<lcm_dmatch*>(flat.data()), flat.size(), offs.data(), nullptr) != LCM_OK)
+        raise("matchLoopClosures");
+    for (size_t i = 0; i < trains.size(); ++i) lists[i].assign(flat.begin() + (ptrdiff_t)offs[i], flat.begin() + (ptrdiff_t)offs[i + 1]);
+    return lists;
+}
+
 void LoopClosingSystem::saveResults(const std::string& output_dir) {
     if (mkdir(output_dir.c_str(), 0777) != 0 && errno != EEXIST)
         throw std::runtime_error("saveResults: cannot create " + output_dir + ": " + strerror(errno));
@@ -187,6 +205,24 @@ int lcs_get_consecutive_matches(const lcs_system* s, lcm_dmatch* out, int cap, i
     if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(lcm_dmatch));
     *n_out = (int)v.size();
     return LCM_OK;
+}
+
+int lcs_match_loop_closures(lcs_system* s, int current_frame_id, lcm_dmatch* out, size_t cap, size_t* offsets, int offsets_cap, int* n_lists) {
+    if (!s || !n_lists || !offsets) return LCM_ERR_INVALID_ARG;
+    *n_lists = 0;
+    return guarded([&] {
+        auto lists = s->sys.matchLoopClosures(current_frame_id);
+        if ((int)lists.size() + 1 > offsets_cap) throw std::invalid_argument("matchLoopClosures: offsets buffer too small");
+        size_t k = 0;
+        for (size_t i = 0; i < lists.size(); ++i) {
+            offsets[i] = k;
+            if (k + lists[i].size() > cap) throw std::invalid_argument("matchLoopClosures: output buffer too small");
+            if (!lists[i].empty()) memcpy(out + k, lists[i].data(), lists[i].size() * sizeof(lcm_dmatch));
+            k += lists[i].size();
+        }
+        offsets[lists.size()] = k;
+        *n_lists = (int)lists.size();
+    });
 }
 
 int lcs_num_frames(const lcs_system* s) { return s ? (int)s->sys.getFrames().size() : 0; }

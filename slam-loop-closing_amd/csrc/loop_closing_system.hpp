@@ -66,6 +66,12 @@ public:
     // BASELINE.json's north_star spells this one detectLoopClosure.
     std::vector<LoopCandidate> detectLoopClosure(int current_frame_id) { return detectLoops(current_frame_id); }
 
+    // "Re-match features on identified loop frames" (README.md:101): the DMatch lists of all loop closures recorded for
+    // `current_frame_id` (same order as they appear in getLoopClosures()), query = that frame, train = the matched
+    // frame — every pair in ONE kernel launch (lcm_match_query_batch).  Only closures whose matched frame this rank
+    // stores can be re-matched (all of them when shard_world == 1).
+    std::vector<std::vector<DMatch>> matchLoopClosures(int current_frame_id);
+
     // Matches between the previous and the current frame, as processFrame's consecutive-frame step computes them
     // (README.md:96-97 "Feature matching between consecutive frames"; what estimatePose / triangulatePoints would consume).
     const std::vector<DMatch>& getConsecutiveMatches() const { return consecutive_matches_; }

@@ -104,6 +104,11 @@ def test_null_handle_calls_fail_cleanly(pkg):
     assert lib.lcm_match_pair(None, buf, 1, buf, 1, buf, buf, C.byref(n)) == -1
     assert lib.lcm_match_features(None, buf, 1, buf, 1, buf, C.byref(n), C.byref(n)) == -1
     assert lib.lcm_match_stored(None, 0, 1, buf, 1, C.byref(n), C.byref(n)) == -1
+    assert lib.lcm_match_stored_batch(None, None, 0, None, 0, C.byref(z), None) == -1
+    assert lib.lcm_match_query_batch(None, buf, 1, None, 0, None, 0, C.byref(z), None) == -1
+    assert lib.lcm_query_submit_batch(None, None, None, None, 1, C.byref(n)) == -1
+    assert lib.lcm_query_collect_batch(None, 0, None, 0, C.byref(z), None) == -1
+    assert lib.lcm_online_stats_read(None, None, 0) == -1
     assert lib.lcm_query_scores(None, buf, 1, 0, buf, buf, C.byref(n)) == -1
     assert lib.lcm_detect_loops(None, 0, buf, 1, 1, buf, 1, C.byref(n)) == -1
     assert lib.lcm_all_vs_all(None, None, None, None, 0, 0, None, 0, C.byref(z), None) == -1

@@ -45,6 +45,17 @@ def test_process_frames_online_equals_oracle(pkg, oracle, tmp_path):
         for f in ("query_idx", "train_idx", "img_idx", "distance"):
             np.testing.assert_array_equal(m[f], om[f])
         assert len(m) == int(want["num_matches"][0])
+        # matchLoopClosures: README.md:101 "Re-match features on identified loop frames" — all of a frame's closures, one launch
+        cur_ids = sorted(set(int(x) for x in want["current_frame_id"]))
+        busiest = max(cur_ids, key=lambda c: int((want["current_frame_id"] == c).sum()))
+        lists = sys_.matchLoopClosures(busiest)
+        mine = want[want["current_frame_id"] == busiest]
+        assert len(lists) == len(mine) >= 1
+        for rec, lst in zip(mine, lists):
+            om, _ = oracle.match_features(fs.frame(busiest), fs.frame(int(rec["matched_frame_id"])), p)
+            np.testing.assert_array_equal(lst, om.astype(lst.dtype))
+            assert len(lst) == int(rec["num_matches"])           # the list IS what num_matches counted
+        assert sys_.matchLoopClosures(0) == []
         # saveResults: README.md:142-165 text format
         out = tmp_path / "loop_closing_results"
         sys_.saveResults(str(out))

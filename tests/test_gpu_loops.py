@@ -478,3 +478,46 @@ def test_micro_batched_online_queries_equal_one_by_one(matcher, oracle, pkg, max
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+def test_batched_match_lists_equal_match_features_per_pair(matcher, oracle, pkg):
+    """lcm_match_stored_batch / lcm_match_query_batch (one launch for all pairs, device-side segment fold) == the
+    oracle's matchFeatures per pair: ragged frames, an empty frame, a 1-row frame, duplicated rows (ties across
+    segment boundaries), a pair of a frame with itself."""
+    fs = pkg.synth.make_frames(30, 1100, seed=61, ragged=True, dup_frac=0.5)
+    fs.counts[4] = 0
+    fs.counts[9] = 1
+    fs.rows[7, 100:400] = fs.rows[7, 500:800]                       # ties 400 rows apart inside a train frame
+    fs.rows[12, :300] = fs.rows[7, 500:800]
+    p = oracle.default_params()
+    try:
+        fill(matcher, fs)
+        pairs = [(20, 2), (12, 7), (7, 12), (25, 4), (4, 25), (9, 11), (11, 9), (7, 7), (29, 0), (12, 7)]
+        lists, mins = matcher.match_stored_batch([(int(fs.ids[a]), int(fs.ids[b])) for a, b in pairs])
+        assert len(lists) == len(pairs)
+        for (a, b), got, md in zip(pairs, lists, mins):
+            want, wmd = oracle.match_features(fs.frame(a), fs.frame(b), p)
+            for f in ("query_idx", "train_idx", "img_idx", "distance"):
+                np.testing.assert_array_equal(got[f], want[f], err_msg=f"pair {(a, b)} field {f}")
+            assert int(md) == (wmd if len(want) else -1)
+            one, omd = matcher.match_stored(int(fs.ids[a]), int(fs.ids[b]))      # the single-pair entry agrees
+            np.testing.assert_array_equal(one, got)
+        # one host query (not stored) against many stored frames
+        q = pkg.synth.make_frames(1, 1500, seed=62).frame(0).copy()
+        q[:200] = fs.rows[7, 500:700]
+        trains = [7, 12, 4, 9, 0, 29]
+        lists, mins = matcher.match_query_batch(q, [int(fs.ids[t]) for t in trains])
+        for t, got, md in zip(trains, lists, mins):
+            want, wmd = oracle.match_features(q, fs.frame(t), p)
+            np.testing.assert_array_equal(got, want.astype(got.dtype))
+            assert int(md) == (wmd if len(want) else -1)
+        # empty batch, unknown id, too small a buffer
+        assert matcher.match_stored_batch([])[0] == []
+        with pytest.raises(pkg.LcmError) as e:
+            matcher.match_stored_batch([(int(fs.ids[1]), 9999)])
+        assert e.value.code == -6
+        with pytest.raises(pkg.LcmError) as e:
+            matcher.match_stored_batch([(int(fs.ids[20]), int(fs.ids[2]))], cap=3)
+        assert e.value.code == -4
+    finally:
+        matcher.clear()
