@@ -64,13 +64,18 @@ typedef enum lcm_status {
 } lcm_status;
 
 /* Parameters the reference leaves to README prose (README.md:108-126).  Defaults (lcm_params_default):
- * ratio=2, dist_floor=0, min_matches=50, sim_threshold=0.15, min_gap=30. */
+ * ratio=2, dist_floor=0, min_matches=50, sim_threshold=0.15, min_gap=30, cross_check=0. */
 typedef struct lcm_params {
     int32_t ratio;          /* good match: d <= max(ratio*min_d, dist_floor)      README.md:117 */
     int32_t dist_floor;     /* README states no floor -> 0 */
     int32_t min_matches;    /* loop needs good_count >= min_matches               README.md:124 */
     int32_t min_gap;        /* compare only frames with cur_id - id >= min_gap    README.md:122, hpp:31 */
     double  sim_threshold;  /* loop needs similarity > sim_threshold (strict)     README.md:123 */
+    int32_t cross_check;    /* BFMatcher crossCheck (src/main.cpp:517 passes false): 0 = off (default);
+                             * 1 = mutual nearest neighbours (recent OpenCV 4.x: the `sidx` test in batchDistance);
+                             * 2 = legacy OpenCV (a query keeps the best train row among those that chose it).
+                             * Version dependent upstream, hence off by default; see oracle/lcm_oracle.h. */
+    int32_t reserved;       /* 0 */
 } lcm_params;
 
 /* One record per (query frame, stored frame) pair: what the device ships back (8 bytes).

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "liblcm_oracle.so")
 
 class OrcParams(C.Structure):
     _fields_ = [("ratio", C.c_int32), ("dist_floor", C.c_int32), ("min_matches", C.c_int32),
-                ("min_gap", C.c_int32), ("sim_threshold", C.c_double)]
+                ("min_gap", C.c_int32), ("sim_threshold", C.c_double), ("cross_check", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 SCORE_DTYPE = np.dtype([("good_count", "<u4"), ("min_dist", "<u2"), ("n_train", "<u2")])
@@ -46,6 +47,8 @@ def lib():
         L.orc_hamming256.argtypes = [_vp, _vp]
         L.orc_bf_match.restype = C.c_int
         L.orc_bf_match.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp]
+        L.orc_bf_match_cross.restype = C.c_int
+        L.orc_bf_match_cross.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]
         L.orc_filter_good.restype = C.c_int
         L.orc_filter_good.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)]
         L.orc_match_features.restype = C.c_int
@@ -98,6 +101,16 @@ def bf_match(q, t):
     d = np.full(q.shape[0], -1, np.int32)
     n = lib().orc_bf_match(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(d))
     return idx[:n], d[:n]
+
+
+def bf_match_cross(q, t, mode):
+    """BFMatcher(NORM_HAMMING, crossCheck=True).match, mode 1 (mutual, recent OpenCV) / 2 (legacy):
+    (train_idx int32[nq] with -1 = unmatched, dist int32[nq])."""
+    q, t = _rows(q), _rows(t)
+    idx = np.full(max(q.shape[0], 1), -1, np.int32)
+    d = np.full(max(q.shape[0], 1), -1, np.int32)
+    lib().orc_bf_match_cross(_p(q), q.shape[0], _p(t), t.shape[0], mode, idx.ctypes.data_as(_vp), d.ctypes.data_as(_vp))
+    return idx[: q.shape[0]], d[: q.shape[0]]
 
 
 def filter_good(dist, ratio=2, dist_floor=0):

@@ -26,6 +26,8 @@ void orc_params_default(orc_params* p) {
     p->min_matches = 50;     /* README.md:124 */
     p->min_gap = 30;         /* README.md:109, include/loop_closing.hpp:31 */
     p->sim_threshold = 0.15; /* README.md:108 */
+    p->cross_check = 0;      /* src/main.cpp:517: BFMatcher(norm, false) */
+    p->reserved = 0;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -64,6 +66,31 @@ int orc_bf_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* tr
     return nq;
 }
 
+int orc_bf_match_cross(const uint8_t* q, int nq, const uint8_t* t, int nt, int mode, int32_t* train_idx, int32_t* dist) {
+    for (int i = 0; i < nq; ++i) { train_idx[i] = -1; dist[i] = INT_MAX; }
+    if (nq <= 0 || nt <= 0) return 0;
+    int32_t* tidx = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt);
+    int32_t* tdist = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt);
+    int32_t* sidx = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+    int32_t* sdist = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+    orc_bf_match(t, nt, q, nq, tidx, tdist);      /* batchDistance(src2, src1): nearest QUERY of every train row */
+    orc_bf_match(q, nq, t, nt, sidx, sdist);      /* batchDistance(src1, src2): nearest TRAIN of every query row */
+    for (int j = 0; j < nt; ++j) {
+        const int i = tidx[j];
+        if (tdist[j] < dist[i] && (mode != 1 || sidx[i] == j)) { dist[i] = tdist[j]; train_idx[i] = j; }
+    }
+    int n = 0;
+    for (int i = 0; i < nq; ++i) n += train_idx[i] >= 0;
+    free(tidx); free(tdist); free(sidx); free(sdist);
+    return n;
+}
+
+/* stage 1 of matchFeatures under the handle's cross_check setting: idx[i] = -1 marks "no match for query i" */
+static void bf_match_any(const uint8_t* q, int nq, const uint8_t* t, int nt, int cross_check, int32_t* idx, int32_t* d) {
+    if (cross_check) orc_bf_match_cross(q, nq, t, nt, cross_check, idx, d);
+    else orc_bf_match(q, nq, t, nt, idx, d);
+}
+
 /* README.md:117: "Distance-based filtering (threshold: 2x minimum distance)".  Inclusive compare (the OpenCV
  * tutorial convention this rule comes from; with '<' and min_d == 0 nothing could ever survive). */
 int orc_filter_good(const int32_t* dist, int n, int ratio, int dist_floor, uint8_t* keep, int* min_dist) {
@@ -91,20 +118,25 @@ int orc_match_features(const uint8_t* q, int nq, const uint8_t* t, int nt, const
     int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
     int32_t* d = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
     uint8_t* keep = (uint8_t*)malloc((size_t)n);
-    orc_bf_match(q, nq, t, nt, idx, d);
+    bf_match_any(q, nq, t, nt, p->cross_check, idx, d);
+    /* the filter sees only the matches that exist (cross-check leaves queries unmatched): compact, filter, expand */
+    int32_t* dm = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t* qi = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    int nm = 0;
+    for (int i = 0; i < n; ++i) if (idx[i] >= 0) { dm[nm] = d[i]; qi[nm] = i; ++nm; }
     int m;
-    orc_filter_good(d, n, p->ratio, p->dist_floor, keep, &m);
+    orc_filter_good(dm, nm, p->ratio, p->dist_floor, keep, &m);
     int k = 0;
-    for (int i = 0; i < n; ++i) {
-        if (!keep[i]) continue;
-        out[k].query_idx = i;
-        out[k].train_idx = idx[i];
+    for (int a = 0; a < nm; ++a) {
+        if (!keep[a]) continue;
+        out[k].query_idx = qi[a];
+        out[k].train_idx = idx[qi[a]];
         out[k].img_idx = 0;
-        out[k].distance = (float)d[i];
+        out[k].distance = (float)dm[a];
         ++k;
     }
     if (min_dist) *min_dist = m;
-    free(idx); free(d); free(keep);
+    free(idx); free(d); free(keep); free(dm); free(qi);
     return k;
 }
 
@@ -113,10 +145,12 @@ void orc_pair_score(const uint8_t* q, int nq, const uint8_t* t, int nt, const or
     if (nq <= 0 || nt <= 0) { out->good_count = 0; out->min_dist = 0xFFFF; return; }
     int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
     int32_t* d = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
-    orc_bf_match(q, nq, t, nt, idx, d);
+    bf_match_any(q, nq, t, nt, p->cross_check, idx, d);
+    int nm = 0;
+    for (int i = 0; i < nq; ++i) if (idx[i] >= 0) d[nm++] = d[i];
     int m;
-    out->good_count = (uint32_t)orc_filter_good(d, nq, p->ratio, p->dist_floor, NULL, &m);
-    out->min_dist = (uint16_t)m;
+    out->good_count = (uint32_t)orc_filter_good(d, nm, p->ratio, p->dist_floor, NULL, &m);
+    out->min_dist = nm > 0 ? (uint16_t)m : (uint16_t)0xFFFF;      /* no match survived the cross-check: an empty pair */
     free(idx); free(d);
 }
 
@@ -250,7 +284,10 @@ typedef struct fast_job {
 
 static void* fast_worker(void* arg) {
     fast_job* jb = (fast_job*)arg;
-    uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(jb->max_rows > 0 ? jb->max_rows : 1));
+    const size_t kcap = (size_t)(jb->max_rows > 0 ? jb->max_rows : 1);
+    uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * kcap);
+    uint64_t* bkeys = jb->p->cross_check ? (uint64_t*)malloc(sizeof(uint64_t) * kcap) : NULL;    /* train -> query */
+    uint64_t* ckeys = jb->p->cross_check ? (uint64_t*)malloc(sizeof(uint64_t) * kcap) : NULL;    /* cross-checked */
     for (size_t k = (size_t)jb->tid; k < jb->n_pairs; k += (size_t)jb->n_threads) {
         int qi = jb->pair_q[k], ti = jb->pair_t[k];
         int nq = jb->counts[qi], nt = jb->counts[ti];
@@ -264,21 +301,36 @@ static void* fast_worker(void* arg) {
         if (jb->use_avx512) best_keys_avx512(q, nq, t, nt, keys); else
 #endif
         best_keys_popcnt64(q, nq, t, nt, keys);
+        const uint64_t* use = keys;
+        if (jb->p->cross_check) {                   /* orc_bf_match_cross on (dist, idx) keys; ~0 = unmatched */
+#if defined(__x86_64__)
+            if (jb->use_avx512) best_keys_avx512(t, nt, q, nq, bkeys); else
+#endif
+            best_keys_popcnt64(t, nt, q, nq, bkeys);
+            for (int i = 0; i < nq; ++i) ckeys[i] = ~0ull;
+            for (int j = 0; j < nt; ++j) {
+                const uint32_t i = (uint32_t)bkeys[j];
+                const uint64_t cand = (bkeys[j] & 0xFFFFFFFF00000000ull) | (uint32_t)j;
+                if ((cand >> 32) < (ckeys[i] >> 32) && (jb->p->cross_check != 1 || (uint32_t)keys[i] == (uint32_t)j)) ckeys[i] = cand;
+            }
+            use = ckeys;
+        }
         uint32_t m = 0xFFFFFFFFu;
-        for (int i = 0; i < nq; ++i) { uint32_t d = (uint32_t)(keys[i] >> 32); if (d < m) m = d; }
+        for (int i = 0; i < nq; ++i) { uint32_t d = (uint32_t)(use[i] >> 32); if (d < m) m = d; }
+        if (m == 0xFFFFFFFFu) { s->good_count = 0; s->min_dist = 0xFFFF; continue; }      /* nothing survived */
         uint32_t thr = (uint32_t)jb->p->ratio * m;
         if ((uint32_t)jb->p->dist_floor > thr) thr = (uint32_t)jb->p->dist_floor;
         uint32_t good = 0, isum = 0;
         for (int i = 0; i < nq; ++i) {
-            const int ok = ((uint32_t)(keys[i] >> 32) <= thr);
+            const int ok = use[i] != ~0ull && ((uint32_t)(use[i] >> 32) <= thr);
             good += (uint32_t)ok;
-            if (ok) isum += (uint32_t)keys[i];      /* low word of the key = trainIdx of the first minimum */
+            if (ok) isum += (uint32_t)use[i];       /* low word of the key = trainIdx */
         }
         s->good_count = good;
         s->min_dist = (uint16_t)m;
         if (jb->idx_sums) jb->idx_sums[k] = isum;
     }
-    free(keys);
+    free(keys); free(bkeys); free(ckeys);
     return NULL;
 }
 

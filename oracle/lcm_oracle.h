@@ -30,6 +30,8 @@ extern "C" {
 typedef struct orc_params {   /* mirrors lcm_params; README.md:108-126 */
     int32_t ratio, dist_floor, min_matches, min_gap;
     double  sim_threshold;
+    int32_t cross_check;      /* 0 = BFMatcher(NORM_HAMMING, crossCheck=false), the default; 1 / 2: orc_bf_match_cross */
+    int32_t reserved;
 } orc_params;
 
 typedef struct orc_score { uint32_t good_count; uint16_t min_dist; uint16_t n_train; } orc_score;
@@ -45,6 +47,17 @@ int orc_hamming256(const uint8_t* a, const uint8_t* b);
  * Scans train rows ascending with a strict '<' update from INT_MAX => FIRST minimum wins.
  * Returns the number of matches (nq, or 0 when nq == 0 or nt == 0). */
 int orc_bf_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* train_idx, int32_t* dist);
+
+/* BFMatcher(NORM_HAMMING, crossCheck = true).match — the one matcher option visible in the tree (src/main.cpp:517
+ * passes `false`).  OpenCV upstream, modules/core/src/batch_distance.cpp, `if (crosscheck)` block: every TRAIN row j
+ * finds its nearest query row tidx[j] (first minimum); then, scanning j ascending, query i = tidx[j] takes j if
+ * tdist[j] < dist[i] (strict, dist starts at INT_MAX).  Recent 4.x releases add `&& sidx[i] == j` (sidx = the forward
+ * nearest train row of query i), which makes the result the MUTUAL nearest neighbours; older releases lack it, so a
+ * query can keep a train row that chose it although the query itself prefers another.  The release that changed it
+ * cannot be verified offline — behaviour is version dependent, hence PARITY UNPINNED and off by default:
+ *     mode 1 = with the sidx test (mutual nearest), mode 2 = without it (legacy).
+ * Unmatched queries get train_idx = -1 (knnMatchImpl drops them: compactResult).  Returns the number matched. */
+int orc_bf_match_cross(const uint8_t* q, int nq, const uint8_t* t, int nt, int mode, int32_t* train_idx, int32_t* dist);
 
 /* README.md:117 "2x minimum distance": keep d <= max(ratio*min_d, dist_floor).  keep may be NULL.
  * Returns the number kept; *min_dist = min over matches (-1 if n == 0). */

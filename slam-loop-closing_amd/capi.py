@@ -27,7 +27,8 @@ class LcmError(RuntimeError):
 
 class Params(C.Structure):
     _fields_ = [("ratio", C.c_int32), ("dist_floor", C.c_int32), ("min_matches", C.c_int32),
-                ("min_gap", C.c_int32), ("sim_threshold", C.c_double)]
+                ("min_gap", C.c_int32), ("sim_threshold", C.c_double), ("cross_check", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Score(C.Structure):

@@ -147,6 +147,8 @@ void lcm_params_default(lcm_params* p) {
     p->min_matches = 50;
     p->min_gap = 30;
     p->sim_threshold = 0.15;
+    p->cross_check = 0;
+    p->reserved = 0;
 }
 
 const char* lcm_last_error(void) { return lcm::last_error().c_str(); }
@@ -217,7 +219,7 @@ void lcm_destroy(lcm_handle* h) {
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     if (h->h_pair_stage) (void)hipHostFree(h->h_pair_stage);
     if (h->h_final_keys) (void)hipHostFree(h->h_final_keys);
-    (void)hipFree(h->d_pair_stage);
+    (void)hipFree(h->d_pair_stage); (void)hipFree(h->d_xq);
     if (h->db_ready) (void)hipEventDestroy(h->db_ready);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -233,6 +235,7 @@ int lcm_set_params(lcm_handle* h, const lcm_params* p) {
     if (p->ratio < 0 || p->dist_floor < 0 || p->min_gap < 0 || p->min_matches < 0) return fail(LCM_ERR_INVALID_ARG, "negative parameter");
     if (p->ratio > 65536 || p->dist_floor > 65536) return fail(LCM_ERR_INVALID_ARG, "ratio / dist_floor above 65536 (distances are <= 256)");
     if (!(p->sim_threshold == p->sim_threshold)) return fail(LCM_ERR_INVALID_ARG, "sim_threshold is NaN");
+    if (p->cross_check < 0 || p->cross_check > 2) return fail(LCM_ERR_INVALID_ARG, "cross_check must be 0, 1 or 2");
     h->params = *p;
     h->plan.key = 0;
     return LCM_OK;
@@ -532,10 +535,40 @@ static int run_pair_jobs(lcm_handle* h, const uint8_t* d_q_base, const uint8_t* 
     return LCM_OK;
 }
 
-// One pair with rows from the host and / or the device: host rows travel inside the staging block (the train matrix with
-// its padding rows — copies of the last row — written straight into pinned memory: no extra copies).
+// Cross-check on shipped keys (integer bookkeeping, O(nq + nt)): fkeys[q] = (d, first nearest train row of q),
+// bkeys[t] = (d, first nearest query row of t) -> keys[q] = the match q keeps, 0xFFFFFFFF = none.  Same rule as
+// k_cross_score / oracle orc_bf_match_cross.
+static void cross_combine(int mode, const uint32_t* fkeys, int nq, const uint32_t* bkeys, int nt, std::vector<uint32_t>& keys) {
+    keys.assign((size_t)nq, 0xFFFFFFFFu);
+    if (mode == 1) {
+        for (int q = 0; q < nq; ++q)
+            if ((int)(bkeys[fkeys[q] & lcm::KEY_IDX_MASK] & lcm::KEY_IDX_MASK) == q) keys[(size_t)q] = fkeys[q];
+    } else {
+        for (int t = 0; t < nt; ++t) {
+            const uint32_t i = bkeys[t] & lcm::KEY_IDX_MASK;
+            const uint32_t cand = (bkeys[t] & ~lcm::KEY_IDX_MASK) | (uint32_t)t;
+            if (cand < keys[i]) keys[i] = cand;       // (dist, t) lexicographic: strict '<' on dist, first t on ties
+        }
+    }
+}
+
+// One pair with rows from the host and / or the device: host rows travel inside the staging block (a matrix in the TRAIN
+// role with its padding rows — copies of the last row — written straight into pinned memory: no extra copies).
+// With cross_check the pair runs twice, roles swapped the second time, and the two key arrays are combined.
 static int pair_keys(lcm_handle* h, RowSrc q, RowSrc t, std::vector<uint32_t>& keys_out) {
     int rc = set_device(h); if (rc) return rc;
+    if (h->params.cross_check) {
+        if (q.n > LCM_MAX_TRAIN_ROWS) return fail(LCM_ERR_CAPACITY, "cross_check: at most %d query rows", LCM_MAX_TRAIN_ROWS);
+        lcm_params saved = h->params;
+        h->params.cross_check = 0;
+        std::vector<uint32_t> fk, bk;
+        rc = pair_keys(h, q, t, fk);
+        if (!rc) rc = pair_keys(h, t, q, bk);
+        h->params = saved;
+        if (rc) return rc;
+        cross_combine(saved.cross_check, fk.data(), q.n, bk.data(), t.n, keys_out);
+        return LCM_OK;
+    }
     const size_t q_bytes = q.dev ? 0 : (size_t)q.n * LCM_DESC_BYTES;
     const size_t t_off = (q_bytes + 255) & ~(size_t)255;
     const size_t t_bytes = t.dev ? 0 : (size_t)(padded_rows(t.n) + ROW_PAD) * LCM_DESC_BYTES;
@@ -577,12 +610,12 @@ static int stored_src(lcm_handle* h, int frame_id, RowSrc* out, int* n_kp) {
 static int filter_keys(const lcm_handle* h, const std::vector<uint32_t>& keys, int nq, lcm_dmatch* out, int* n_out, int* min_dist) {
     // README.md:117 filter on the shipped integers (O(nq) bookkeeping)
     uint32_t m = 0xFFFFFFFFu;
-    for (int i = 0; i < nq; ++i) m = std::min(m, keys[i] >> lcm::KEY_SHIFT);
+    for (int i = 0; i < nq; ++i) if (keys[i] != 0xFFFFFFFFu) m = std::min(m, keys[i] >> lcm::KEY_SHIFT);
     const uint32_t thr = std::max((uint32_t)h->params.ratio * m, (uint32_t)h->params.dist_floor);
     int k = 0;
     for (int i = 0; i < nq; ++i) {
         const uint32_t d = keys[i] >> lcm::KEY_SHIFT;
-        if (d <= thr) {
+        if (keys[i] != 0xFFFFFFFFu && d <= thr) {      // 0xFFFFFFFF: the cross-check left this query unmatched
             out[k].query_idx = i;
             out[k].train_idx = (int32_t)(keys[i] & lcm::KEY_IDX_MASK);
             out[k].img_idx = 0;
@@ -591,7 +624,7 @@ static int filter_keys(const lcm_handle* h, const std::vector<uint32_t>& keys, i
         }
     }
     *n_out = k;
-    if (min_dist) *min_dist = (int)m;
+    if (min_dist) *min_dist = m == 0xFFFFFFFFu ? -1 : (int)m;
     return LCM_OK;
 }
 
@@ -603,11 +636,14 @@ static int match_pair_impl(lcm_handle* h, const uint8_t* query, int nq, const ui
     if (!query || !train || !train_idx || !dist) return fail(LCM_ERR_INVALID_ARG, "NULL buffer");
     std::vector<uint32_t> keys;
     int rc = pair_keys(h, RowSrc{query, nullptr, nq}, RowSrc{train, nullptr, nt}, keys); if (rc) return rc;
+    int n = 0;
     for (int i = 0; i < nq; ++i) {
+        if (keys[i] == 0xFFFFFFFFu) { train_idx[i] = -1; dist[i] = 0xFFFF; continue; }   // cross_check: no match for row i
         train_idx[i] = (int32_t)(keys[i] & lcm::KEY_IDX_MASK);
         dist[i] = (uint16_t)(keys[i] >> lcm::KEY_SHIFT);
+        ++n;
     }
-    if (n_matches) *n_matches = nq;
+    if (n_matches) *n_matches = h->params.cross_check ? n : nq;
     return LCM_OK;
 }
 
@@ -641,12 +677,12 @@ static int match_stored_impl(lcm_handle* h, int query_frame_id, int train_frame_
 // Keys of one job -> its DMatch list appended at out[*n_total ...] (README.md:117 filter, query order kept).
 static int emit_matches(const lcm_handle* h, const uint32_t* keys, int nq, lcm_dmatch* out, size_t cap, size_t* n_total, int32_t* min_dist) {
     uint32_t m = 0xFFFFFFFFu;
-    for (int i = 0; i < nq; ++i) m = std::min(m, keys[i] >> lcm::KEY_SHIFT);
+    for (int i = 0; i < nq; ++i) if (keys[i] != 0xFFFFFFFFu) m = std::min(m, keys[i] >> lcm::KEY_SHIFT);
     const uint32_t thr = std::max((uint32_t)h->params.ratio * m, (uint32_t)h->params.dist_floor);
     size_t k = *n_total;
     for (int i = 0; i < nq; ++i) {
         const uint32_t d = keys[i] >> lcm::KEY_SHIFT;
-        if (d <= thr) {
+        if (keys[i] != 0xFFFFFFFFu && d <= thr) {
             if (k >= cap) return fail(LCM_ERR_CAPACITY, "match buffer holds %zu records: too small", cap);
             out[k].query_idx = i;
             out[k].train_idx = (int32_t)(keys[i] & lcm::KEY_IDX_MASK);
@@ -656,7 +692,7 @@ static int emit_matches(const lcm_handle* h, const uint32_t* keys, int nq, lcm_d
         }
     }
     *n_total = k;
-    if (min_dist) *min_dist = nq > 0 ? (int32_t)m : -1;
+    if (min_dist) *min_dist = m == 0xFFFFFFFFu ? -1 : (int32_t)m;
     return LCM_OK;
 }
 
@@ -690,13 +726,37 @@ static int match_batch_impl(lcm_handle* h, const uint8_t* q_host, int nq_host, c
     const uint32_t* keys = nullptr;
     std::vector<size_t> row0;
     rc = run_pair_jobs(h, h->d_rows, h->d_rows, q_host != nullptr, false, stage_bytes, jobs, &keys, row0); if (rc) return rc;
+    std::vector<uint32_t> fwd, bwd_all, ck;
+    std::vector<size_t> brow0;
+    if (h->params.cross_check && !jobs.empty()) {
+        // second pass, roles swapped: every train row's first nearest QUERY row.  A host query travels again, this time
+        // with the padding rows the train role needs.
+        fwd.assign(keys, keys + row0.back());
+        std::vector<PairJob> back(jobs.size());
+        size_t bstage = 0;
+        if (q_host) {
+            const int np = padded_rows(nq_host) + ROW_PAD;
+            bstage = (size_t)np * LCM_DESC_BYTES;
+            rc = ensure_pinned(h->h_pair_stage, h->h_pair_stage_bytes, bstage + 65536 + (size_t)n_pairs * 2048); if (rc) return rc;
+            memcpy(h->h_pair_stage, q_host, (size_t)nq_host * LCM_DESC_BYTES);
+            for (int r = nq_host; r < np; ++r) memcpy(h->h_pair_stage + (size_t)r * LCM_DESC_BYTES, q_host + (size_t)(nq_host - 1) * LCM_DESC_BYTES, LCM_DESC_BYTES);
+        }
+        for (size_t j = 0; j < jobs.size(); ++j) back[j] = {jobs[j].t_row, jobs[j].nt, jobs[j].q_row, jobs[j].nq};
+        rc = run_pair_jobs(h, h->d_rows, h->d_rows, false, q_host != nullptr, bstage, back, &keys, brow0); if (rc) return rc;
+        bwd_all.assign(keys, keys + brow0.back());
+    }
     size_t total = 0;
     for (int p = 0; p < n_pairs; ++p) {
         offsets[p] = total;
         if (min_dists) min_dists[p] = -1;
         const int j = job_of[(size_t)p];
         if (j < 0) continue;
-        rc = emit_matches(h, keys + row0[(size_t)j], jobs[(size_t)j].nq, out, out ? cap : 0, &total, min_dists ? &min_dists[p] : nullptr);
+        const uint32_t* kp = keys + row0[(size_t)j];
+        if (h->params.cross_check) {
+            cross_combine(h->params.cross_check, fwd.data() + row0[(size_t)j], jobs[(size_t)j].nq, bwd_all.data() + brow0[(size_t)j], jobs[(size_t)j].nt, ck);
+            kp = ck.data();
+        }
+        rc = emit_matches(h, kp, jobs[(size_t)j].nq, out, out ? cap : 0, &total, min_dists ? &min_dists[p] : nullptr);
         if (rc) return rc;
     }
     offsets[n_pairs] = total;
@@ -722,6 +782,81 @@ static void account_prefix(lcm_handle* h, int nq, int n_elig) {
     h->info.pairs = (uint64_t)n_elig; h->info.distances = dist; h->info.algo_bytes = bytes;
 }
 
+// cross_check scoring of "query c against stored slots [0, elig[c])" for n_q queries, records written to d_scores in
+// (query, slot) order starting at index 0.  Query c is nq[c] rows starting at row q_row0[c] of the matrix at d_qbase,
+// padded for the train role.  Per chunk of pairs (bounded key scratch): forward keys (query rows -> stored frame),
+// backward keys (stored rows -> query frame: roles swapped), k_cross_score folds both into the score record on the device.
+static int cross_score_prefixes(lcm_handle* h, const uint8_t* d_qbase, const uint32_t* q_row0, const int* nq, const int* elig,
+                                int n_q, lcm_score* d_scores, uint32_t* d_idx_sums) {
+    const int CH = lcm::MAX_FUSED_QUERY_ROWS;
+    constexpr size_t SLOT_BUDGET = 49152;                 // key slots of 8 KB per chunk: 384 MB of scratch
+    std::vector<lcm::PairItem> fitems, bitems;
+    std::vector<lcm::CrossDesc> descs;
+    size_t slots = 0;
+    int max_fq = 0, max_bq = 0;
+    uint64_t dist = 0, bytes = 0, pairs = 0;
+    uint32_t out = 0, launches = 0;
+    auto flush = [&]() -> int {
+        if (descs.empty()) return LCM_OK;
+        const size_t off_b = sizeof(lcm::PairItem) * fitems.size();
+        const size_t off_d = off_b + sizeof(lcm::PairItem) * bitems.size();
+        const size_t up = off_d + sizeof(lcm::CrossDesc) * descs.size();
+        int rc = ensure_pinned(h->h_pair_stage, h->h_pair_stage_bytes, up); if (rc) return rc;
+        rc = ensure_dev(h->d_pair_stage, h->d_pair_stage_bytes, up, ARENA_SLACK); if (rc) return rc;
+        rc = ensure_dev(h->d_keys, h->d_keys_n, slots * (size_t)CH); if (rc) return rc;
+        memcpy(h->h_pair_stage, fitems.data(), off_b);
+        memcpy(h->h_pair_stage + off_b, bitems.data(), off_d - off_b);
+        memcpy(h->h_pair_stage + off_d, descs.data(), up - off_d);
+        HIP_TRY(hipMemcpyAsync(h->d_pair_stage, h->h_pair_stage, up, hipMemcpyHostToDevice, h->stream));
+        lcm::ScoreArgs a{};
+        a.scores = nullptr; a.keys = h->d_keys; a.keys_stride = CH;
+        a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
+        a.q_rows = (const uint32_t*)d_qbase; a.db_rows = (const uint32_t*)h->d_rows;
+        a.pair_items = reinterpret_cast<const lcm::PairItem*>(h->d_pair_stage);
+        hipError_t e = lcm::launch_score(a, (uint32_t)fitems.size(), max_fq, true, 0, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        a.q_rows = (const uint32_t*)h->d_rows; a.db_rows = (const uint32_t*)d_qbase;
+        a.pair_items = reinterpret_cast<const lcm::PairItem*>(h->d_pair_stage + off_b);
+        e = lcm::launch_score(a, (uint32_t)bitems.size(), max_bq, true, 0, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        lcm::CrossArgs c{};
+        c.keys = h->d_keys; c.descs = reinterpret_cast<const lcm::CrossDesc*>(h->d_pair_stage + off_d);
+        c.scores = d_scores; c.idx_sums = d_idx_sums;
+        c.mode = h->params.cross_check; c.ratio = h->params.ratio; c.dist_floor = h->params.dist_floor;
+        e = lcm::launch_cross_score(c, (uint32_t)descs.size(), h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "cross-check kernel launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipStreamSynchronize(h->stream));        // the staging block is rewritten by the next chunk
+        launches += 3;
+        fitems.clear(); bitems.clear(); descs.clear(); slots = 0; max_fq = max_bq = 0;
+        return LCM_OK;
+    };
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    for (int c = 0; c < n_q; ++c) {
+        if (nq[c] > CH) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", CH);
+        bytes += (uint64_t)nq[c] * 32;
+        for (int s = 0; s < elig[c]; ++s) {
+            const int nt = h->frames[(size_t)s].n;
+            const size_t need = 1 + (size_t)((nt + CH - 1) / CH);
+            if (slots + need > SLOT_BUDGET) { const int rc = flush(); if (rc) return rc; }
+            const uint32_t t_row0 = (uint32_t)((size_t)s * (size_t)h->stride_rows);
+            lcm::CrossDesc d{(uint32_t)slots, (uint32_t)slots + 1, (uint32_t)nq[c], (uint32_t)nt, out++};
+            fitems.push_back({q_row0[c], t_row0, (uint32_t)nq[c] | ((uint32_t)nt << 12), (uint32_t)slots});
+            for (int k = 0; k * CH < nt; ++k)
+                bitems.push_back({t_row0 + (uint32_t)(k * CH), q_row0[c], (uint32_t)std::min(CH, nt - k * CH) | ((uint32_t)nq[c] << 12), (uint32_t)(slots + 1 + (size_t)k)});
+            descs.push_back(d);
+            slots += need;
+            max_fq = std::max(max_fq, nq[c]); max_bq = std::max(max_bq, std::min(CH, nt));
+            dist += 2ull * (uint64_t)nq[c] * (uint64_t)nt; bytes += 2ull * (uint64_t)nt * 32 + 8; ++pairs;
+        }
+    }
+    { const int rc = flush(); if (rc) return rc; }
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    h->info_pending = true;
+    h->info.launches = launches; h->info.workgroups = 0;
+    h->info.pairs = pairs; h->info.distances = dist; h->info.algo_bytes = bytes;
+    return LCM_OK;
+}
+
 // Enqueue (no host synchronisation) the scoring of ONE query frame — `nq` rows at device address d_q — against stored
 // slots [0, n_elig), and the download of the n_elig score records into the slot's pinned buffer.  Work items are
 // implicit (derived from blockIdx), so nothing but the query itself crosses PCIe.  Short databases use the split
@@ -731,6 +866,19 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
     q.acc_pairs = q.acc_distances = q.acc_bytes = 0; q.acc_launches = 0; q.acc_queries = 1;
     if (n_elig <= 0) { HIP_TRY(hipEventRecord(q.done, h->stream)); return LCM_OK; }
     int rc = wait_db(h); if (rc) return rc;
+    if (h->params.cross_check) {
+        // both directions + the on-device mutual test; the caller has padded the query rows for the train role
+        rc = ensure_dev(q.d_scores, q.d_scores_n, (size_t)n_elig); if (rc) return rc;
+        rc = ensure_pinned(q.h_scores, q.h_scores_n, (size_t)n_elig); if (rc) return rc;
+        const uint32_t row0 = 0;
+        HIP_TRY(hipEventRecord(q.k0, h->stream));
+        rc = cross_score_prefixes(h, (const uint8_t*)d_q, &row0, &nq, &n_elig, 1, q.d_scores, nullptr); if (rc) return rc;
+        HIP_TRY(hipEventRecord(q.k1, h->stream));
+        q.acc_pairs = h->info.pairs; q.acc_distances = h->info.distances; q.acc_bytes = h->info.algo_bytes; q.acc_launches = h->info.launches;
+        HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(q.done, h->stream));
+        return LCM_OK;
+    }
     const int split_env = h->tune_online_split;              // lcm_set_tuning(LCM_TUNE_ONLINE_SPLIT); -1 = automatic
     int qpt = 0;
     if (h->variant == 0 && nq > 512) {
@@ -801,6 +949,19 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
     if (total == 0) { HIP_TRY(hipEventRecord(q.done, h->stream)); return LCM_OK; }
     if (total > 0x7FFFFFFFull) return fail(LCM_ERR_CAPACITY, "more than 2^31 pairs in one batch");
     int rc = wait_db(h); if (rc) return rc;
+    if (h->params.cross_check) {
+        rc = ensure_dev(q.d_scores, q.d_scores_n, total); if (rc) return rc;
+        rc = ensure_pinned(q.h_scores, q.h_scores_n, total); if (rc) return rc;
+        uint32_t row0[lcm::MAX_QUERY_BATCH];
+        for (int b = 0; b < B; ++b) row0[b] = (uint32_t)(b * rows_per_query);
+        HIP_TRY(hipEventRecord(q.k0, h->stream));
+        rc = cross_score_prefixes(h, (const uint8_t*)d_q, row0, nq, elig, B, q.d_scores, nullptr); if (rc) return rc;
+        HIP_TRY(hipEventRecord(q.k1, h->stream));
+        q.acc_pairs = h->info.pairs; q.acc_distances = h->info.distances; q.acc_bytes = h->info.algo_bytes; q.acc_launches = h->info.launches;
+        HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * total, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(q.done, h->stream));
+        return LCM_OK;
+    }
     int qpt = 0;
     if (max_nq > 512) {
         if (h->tune_online_split >= 0) qpt = h->tune_online_split;
@@ -922,12 +1083,16 @@ static int query_submit_impl(lcm_handle* h, const uint8_t* query, int nq, int qu
     QuerySlot& q = h->qslots[t];
     q.query_id = query_frame_id;
     const int n_elig = eligible_prefix(h, query_frame_id, h->params.min_gap);
-    const size_t bytes = (size_t)std::max(nq, 1) * LCM_DESC_BYTES;
+    // cross_check scores the pair in both directions: the query rows then also serve in the TRAIN role and need its
+    // padding rows (copies of the last row)
+    const int rows_up = h->params.cross_check ? padded_rows(nq) + ROW_PAD : nq;
+    const size_t bytes = (size_t)std::max(rows_up, 1) * LCM_DESC_BYTES;
     rc = ensure_pinned(q.h_query, q.h_query_bytes, bytes); if (rc) return rc;
     rc = ensure_dev(q.d_query, q.d_query_bytes, bytes, ARENA_SLACK); if (rc) return rc;
     if (nq > 0 && n_elig > 0) {
         memcpy(q.h_query, query, (size_t)nq * LCM_DESC_BYTES);       // the caller's buffer is free when we return
-        HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, (size_t)nq * LCM_DESC_BYTES, hipMemcpyHostToDevice, h->stream));
+        for (int r = nq; r < rows_up; ++r) memcpy(q.h_query + (size_t)r * LCM_DESC_BYTES, query + (size_t)(nq - 1) * LCM_DESC_BYTES, LCM_DESC_BYTES);
+        HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, (size_t)rows_up * LCM_DESC_BYTES, hipMemcpyHostToDevice, h->stream));
     }
     rc = enqueue_query(h, q, (const uint32_t*)q.d_query, nq, n_elig); if (rc) return rc;
     q.busy = true;
@@ -994,12 +1159,18 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
         }
         if (qpt == 1 || qpt == 2 || qpt == 4) pitch = round_up(max_nq, 256 * qpt);
     }
+    if (h->params.cross_check) pitch = padded_rows(std::max(max_nq, 1)) + 2 * ROW_PAD;   // room for every query's padding rows
     const size_t bytes = (size_t)pitch * (size_t)n_queries * LCM_DESC_BYTES;
     rc = ensure_pinned(q.h_query, q.h_query_bytes, bytes); if (rc) return rc;
     rc = ensure_dev(q.d_query, q.d_query_bytes, bytes, ARENA_SLACK); if (rc) return rc;
     if (total > 0) {
         for (int b = 0; b < n_queries; ++b)          // the callers' buffers are free when we return
-            if (nq[b] > 0) memcpy(q.h_query + (size_t)b * pitch * LCM_DESC_BYTES, queries[b], (size_t)nq[b] * LCM_DESC_BYTES);
+            if (nq[b] > 0) {
+                uint8_t* dst = q.h_query + (size_t)b * pitch * LCM_DESC_BYTES;
+                memcpy(dst, queries[b], (size_t)nq[b] * LCM_DESC_BYTES);
+                if (h->params.cross_check)
+                    for (int r = nq[b]; r < padded_rows(nq[b]) + ROW_PAD; ++r) memcpy(dst + (size_t)r * LCM_DESC_BYTES, queries[b] + (size_t)(nq[b] - 1) * LCM_DESC_BYTES, LCM_DESC_BYTES);
+            }
         HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, bytes, hipMemcpyHostToDevice, h->stream));
     }
     rc = enqueue_batch(h, q, (const uint32_t*)q.d_query, pitch, n_queries, nq, elig); if (rc) return rc;
@@ -1193,6 +1364,31 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     if (P.n_pairs == 0) return LCM_OK;
 
     rc = wait_db(h); if (rc) return rc;
+    if (h->params.cross_check) {
+        // BFMatcher crossCheck: every pair is matched in both directions and folded on the device
+        std::vector<uint32_t> row0((size_t)n_q_frames);
+        std::vector<int> nqv((size_t)n_q_frames), ev((size_t)n_q_frames);
+        const uint8_t* qbase = h->d_rows;
+        uint32_t pitch = (uint32_t)h->stride_rows;
+        if (!self) {
+            // the caller's rows carry no train-role padding: work on a padded copy
+            pitch = (uint32_t)(padded_rows(q_stride_rows) + 2 * ROW_PAD);
+            uint32_t n_slots = 0;
+            for (int c = 0; c < n_q_frames; ++c) n_slots = std::max(n_slots, (q_frame_of ? q_frame_of[c] : (uint32_t)c) + 1);
+            rc = ensure_dev(h->d_xq, h->d_xq_bytes, (size_t)n_slots * pitch * LCM_DESC_BYTES, ARENA_SLACK); if (rc) return rc;
+            HIP_TRY(hipMemcpy2DAsync(h->d_xq, (size_t)pitch * LCM_DESC_BYTES, d_query_rows, (size_t)q_stride_rows * LCM_DESC_BYTES,
+                                     (size_t)q_stride_rows * LCM_DESC_BYTES, n_slots, hipMemcpyDeviceToDevice, h->stream));
+            hipError_t e = lcm::launch_pad_rows((uint32_t*)h->d_xq, d_query_counts, pitch, n_slots, h->stream);
+            if (e != hipSuccess) return fail(LCM_ERR_HIP, "pad kernel launch failed: %s", hipGetErrorString(e));
+            qbase = h->d_xq;
+        }
+        for (int c = 0; c < n_q_frames; ++c) {
+            row0[(size_t)c] = (q_frame_of ? q_frame_of[c] : (uint32_t)c) * pitch;
+            nqv[(size_t)c] = self ? h->frames[(size_t)c].n : qc[(size_t)c];
+            ev[(size_t)c] = (int)(P.offsets[(size_t)c + 1] - P.offsets[(size_t)c]);
+        }
+        return cross_score_prefixes(h, qbase, row0.data(), nqv.data(), ev.data(), n_q_frames, (lcm_score*)d_scores, d_idx_sums);
+    }
     lcm::ScoreArgs a{};
     a.q_rows = self ? (const uint32_t*)h->d_rows : (const uint32_t*)d_query_rows;
     a.q_counts = self ? h->d_counts : d_query_counts;

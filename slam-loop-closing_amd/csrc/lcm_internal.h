@@ -125,6 +125,7 @@ struct lcm_handle {
     uint8_t* h_pair_stage = nullptr; size_t h_pair_stage_bytes = 0;   // pair mode: pinned [rows | items | descriptors]
     uint8_t* d_pair_stage = nullptr; size_t d_pair_stage_bytes = 0;
     uint32_t* h_final_keys = nullptr; size_t h_final_keys_n = 0;      // pair mode: pinned landing zone of the folded keys
+    uint8_t* d_xq = nullptr; size_t d_xq_bytes = 0;                   // cross_check: padded copy of an external query set
     lcm_score* d_bulk_scores = nullptr; size_t d_bulk_scores_n = 0;   // lcm_all_vs_all_loops: scores stay on the device
     size_t bulk_scores_valid = 0;                                     // records of the last fused call still in there
     int32_t* d_meta = nullptr; size_t d_meta_n = 0;

@@ -124,6 +124,30 @@ struct LoopTestArgs {
 };
 hipError_t launch_loop_test(const LoopTestArgs& a, hipStream_t st);
 
+// Cross-check (lcm_params.cross_check, BFMatcher crossCheck = true): per pair, forward keys (every query row's first
+// nearest train row) and backward keys (every train row's first nearest query row) -> the pair's score record.
+//   mode 1 (mutual):  query q keeps (d, j) = fkey[q] iff bkey[j].idx == q
+//   mode 2 (legacy):  query q keeps min over the train rows t with bkey[t].idx == q of (bkey[t].dist, t)
+// then the usual min-of-mins / ratio filter / count over the queries that kept a match.
+struct CrossDesc {
+    uint32_t f_slot;             // forward keys at keys + f_slot * MAX_FUSED_QUERY_ROWS (nq <= 2048 entries)
+    uint32_t b_slot;             // backward keys at keys + b_slot * MAX_FUSED_QUERY_ROWS (nt entries, contiguous)
+    uint32_t nq, nt;
+    uint32_t out;                // record index in scores
+};
+struct CrossArgs {
+    const uint32_t*  keys;
+    const CrossDesc* descs;
+    void*            scores;
+    uint32_t*        idx_sums;   // optional
+    int32_t          mode, ratio, dist_floor;
+};
+hipError_t launch_cross_score(const CrossArgs& a, uint32_t n_pairs, hipStream_t st);
+
+// Give every frame of a row matrix the padding the TRAIN role needs: rows [n, round_up(n, 4) + 4) of frame f become
+// copies of its row n - 1 (n = counts[f]; nothing is written for n == 0).  stride_rows >= round_up(max n, 4) + 4.
+hipError_t launch_pad_rows(uint32_t* rows, const int32_t* counts, uint32_t stride_rows, uint32_t n_frames, hipStream_t st);
+
 // Multi-GPU merge (lcm_group_*): the W per-shard score arrays, gathered back to back on one device, are un-permuted
 // into the single-device (query ascending, stored ascending) order.  Shard r's records are in (query ascending, owned
 // stored ascending) order; query c's k-th record of shard r is stored position r + k * W, so it lands at

@@ -150,14 +150,21 @@ __device__ __forceinline__ uint32_t rescan_distance(const uint32_t (&q)[8], cons
 // ---------------------------------------------------------------------------------------------------
 constexpr int ARGMIN_GROUP = 16;      // train rows per (dist, group) key; a multiple of the 4 rows of one loop trip
 
-template <int THREADS, int QPT, bool ARGMIN, bool WRITE_KEYS>
+// ARGMIN_MODE: 0 = distances only; 1 = argmin by group keys + re-scan (bulk: throughput, the re-scan's dependent loads
+// hide behind the other waves); 2 = argmin by a packed key per distance (v_lshl_or_b32 per distance, +8 % VALU, no
+// re-scan: the pair mode, where a launch is a few dozen workgroups and the re-scan's ~250 dependent loads per lane
+// would be most of its latency).
+template <int THREADS, int QPT, int ARGMIN_MODE, bool WRITE_KEYS>
 __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
-    // ARGMIN = false with WRITE_KEYS = true writes the best DISTANCE per query row (split mode, see k_finalize_pairs)
+    // ARGMIN_MODE = 0 with WRITE_KEYS = true writes the best DISTANCE per query row (split mode, see k_finalize_pairs)
+    constexpr bool ARGMIN = ARGMIN_MODE != 0;
+    constexpr bool GROUPED = ARGMIN_MODE == 1;
+    constexpr bool KEYED = ARGMIN_MODE == 2;
     constexpr int DSHIFT = ARGMIN ? KEY_SHIFT : 0;      // best[j] >> DSHIFT is the best distance (epilogue)
     __shared__ uint32_t red_min[2];
     __shared__ uint32_t red_sum[2];
     __shared__ uint32_t red_idx[2];
-    __shared__ uint32_t lane_key[ARGMIN ? THREADS * QPT : 1];
+    __shared__ uint32_t lane_key[GROUPED ? THREADS * QPT : 1];
 
     const int tid = threadIdx.x;
     if (tid == 0) { red_min[0] = red_min[1] = 0xFFFFFFFFu; red_sum[0] = red_sum[1] = 0u; red_idx[0] = red_idx[1] = 0u; }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
         uint32_t best[QPT];
 #pragma unroll
         for (int j = 0; j < QPT; ++j) best[j] = 0xFFFFFFFFu;
-        if (ARGMIN) {
+        if (GROUPED) {
 #pragma unroll
             for (int j = 0; j < QPT; ++j) lane_key[j * THREADS + tid] = 0xFFFFFFFFu;
         }
@@ -244,19 +251,23 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
                 for (int k = 0; k < 16; ++k) B[k] = T[(t + 2) * 8 + k];
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the VALU block it overlaps
 #pragma unroll
-                for (int j = 0; j < QPT; ++j) fold2_min(best[j], q[j], A);
+                for (int j = 0; j < QPT; ++j) {
+                    if (KEYED) fold2(best[j], q[j], A, (uint32_t)t, (uint32_t)(t + 1)); else fold2_min(best[j], q[j], A);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): B landed while A was being consumed
 #pragma unroll
                 for (int k = 0; k < 16; ++k) A[k] = T[(t + 4) * 8 + k];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < QPT; ++j) fold2_min(best[j], q[j], B);
+                for (int j = 0; j < QPT; ++j) {
+                    if (KEYED) fold2(best[j], q[j], B, (uint32_t)(t + 2), (uint32_t)(t + 3)); else fold2_min(best[j], q[j], B);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (ARGMIN && (t & (ARGMIN_GROUP - 4)) == (ARGMIN_GROUP - 4)) fold_group((uint32_t)t / ARGMIN_GROUP);
+                if (GROUPED && (t & (ARGMIN_GROUP - 4)) == (ARGMIN_GROUP - 4)) fold_group((uint32_t)t / ARGMIN_GROUP);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // A (rows t+4, t+5) landed while B was being consumed
             }
-            if (ARGMIN) {
+            if (GROUPED) {
                 // the last, possibly partial group (a repeat of an already folded group changes nothing) ...
                 fold_group((uint32_t)(nt - 1) / ARGMIN_GROUP);
                 // ... then the re-scan of each query row's winning group for the first row that attains the minimum
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (ARGMIN) {        // from here on best[j] is the packed key dist << 22 | first train row (0xFFFFFFFF: no train rows)
+        if (GROUPED) {       // from here on best[j] is the packed key dist << 22 | first train row (0xFFFFFFFF: no train rows)
 #pragma unroll
             for (int j = 0; j < QPT; ++j) best[j] = lane_key[j * THREADS + tid];
         }
@@ -499,14 +510,14 @@ static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool writ
     if (n_items == 0) return hipSuccess;
     // 78-80 VGPRs (QPT = 8) => 6 waves per SIMD by the register file alone: no other occupancy control is needed
     const unsigned lds = 0;
-    if (write_keys && argmin)
-        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true, true>), dim3(n_items), dim3(THREADS), lds, st, a);
-    else if (write_keys)
-        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, false, true>), dim3(n_items), dim3(THREADS), lds, st, a);
-    else if (argmin)
-        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, true, false>), dim3(n_items), dim3(THREADS), lds, st, a);
+    if (write_keys && argmin)        // pair mode / match lists: a key per distance, no re-scan (latency)
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, 2, true>), dim3(n_items), dim3(THREADS), lds, st, a);
+    else if (write_keys)             // split mode: best distance per query row
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, 0, true>), dim3(n_items), dim3(THREADS), lds, st, a);
+    else if (argmin)                 // bulk argmin: group keys + re-scan (throughput)
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, 1, false>), dim3(n_items), dim3(THREADS), lds, st, a);
     else
-        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, false, false>), dim3(n_items), dim3(THREADS), lds, st, a);
+        hipLaunchKernelGGL((k_score_rowlane<THREADS, QPT, 0, false>), dim3(n_items), dim3(THREADS), lds, st, a);
     return hipGetLastError();
 }
 
@@ -666,6 +677,77 @@ hipError_t launch_loop_test(const LoopTestArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_loop_count, dim3(n_blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, a.block_counts, n_blocks, a.counter);
     hipLaunchKernelGGL(k_loop_emit, dim3(n_blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_cross_score(CrossArgs a) {
+    __shared__ uint32_t ck[MAX_FUSED_QUERY_ROWS];      // per query row: the key it keeps, 0xFFFFFFFF = no match
+    __shared__ uint32_t red_min, red_sum, red_idx;
+    const CrossDesc p = a.descs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const uint32_t* fk = a.keys + (size_t)p.f_slot * MAX_FUSED_QUERY_ROWS;
+    const uint32_t* bk = a.keys + (size_t)p.b_slot * MAX_FUSED_QUERY_ROWS;
+    for (uint32_t q = tid; q < p.nq; q += 256) ck[q] = 0xFFFFFFFFu;
+    if (tid == 0) { red_min = 0xFFFFFFFFu; red_sum = 0u; red_idx = 0u; }
+    __syncthreads();
+    if (p.nt > 0) {
+        if (a.mode == 1) {
+            for (uint32_t q = tid; q < p.nq; q += 256) {
+                const uint32_t f = fk[q];
+                if ((bk[f & KEY_IDX_MASK] & KEY_IDX_MASK) == q) ck[q] = f;
+            }
+        } else {
+            for (uint32_t t = tid; t < p.nt; t += 256) {
+                const uint32_t b = bk[t];
+                atomicMin(&ck[b & KEY_IDX_MASK], (b & ~KEY_IDX_MASK) | t);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t dmin = 0xFFFFFFFFu;
+    for (uint32_t q = tid; q < p.nq; q += 256) if (ck[q] != 0xFFFFFFFFu) dmin = min(dmin, ck[q] >> KEY_SHIFT);
+    atomicMin(&red_min, dmin);
+    __syncthreads();
+    dmin = red_min;
+    const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
+    uint32_t cnt = 0, isum = 0;
+    for (uint32_t q = tid; q < p.nq; q += 256) {
+        const uint32_t k = ck[q];
+        const bool good = k != 0xFFFFFFFFu && (k >> KEY_SHIFT) <= thr;
+        cnt += good ? 1u : 0u;
+        isum += good ? (k & KEY_IDX_MASK) : 0u;
+    }
+    atomicAdd(&red_sum, cnt);
+    atomicAdd(&red_idx, isum);
+    __syncthreads();
+    if (tid == 0) {
+        const bool empty = p.nq == 0 || p.nt == 0 || dmin == 0xFFFFFFFFu;     // nothing survived the cross-check
+        uint2 rec;
+        rec.x = empty ? 0u : red_sum;
+        rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((p.nt & 0xFFFFu) << 16);
+        reinterpret_cast<uint2*>(a.scores)[p.out] = rec;
+        if (a.idx_sums) a.idx_sums[p.out] = empty ? 0u : red_idx;
+    }
+}
+
+hipError_t launch_cross_score(const CrossArgs& a, uint32_t n_pairs, hipStream_t st) {
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cross_score, dim3(n_pairs), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void k_pad_rows(uint32_t* rows, const int32_t* counts, uint32_t stride_rows) {
+    const int n = counts[blockIdx.x];
+    if (n <= 0 || (uint32_t)n > stride_rows) return;        // empty frame, or a slot the caller never filled
+    uint32_t* f = rows + (size_t)blockIdx.x * stride_rows * 8;
+    const int r = n + (int)(threadIdx.x >> 3), w = (int)(threadIdx.x & 7);      // up to 8 rows x 8 dwords
+    const int end = ((n + 3) & ~3) + 4;
+    if (r < end && (uint32_t)r < stride_rows) f[(size_t)r * 8 + w] = f[(size_t)(n - 1) * 8 + w];
+}
+
+hipError_t launch_pad_rows(uint32_t* rows, const int32_t* counts, uint32_t stride_rows, uint32_t n_frames, hipStream_t st) {
+    if (n_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pad_rows, dim3(n_frames), dim3(64), 0, st, rows, counts, stride_rows);
     return hipGetLastError();
 }
 

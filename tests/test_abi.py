@@ -40,7 +40,8 @@ def test_struct_layouts_match_reference_types(pkg):
     assert ctypes.sizeof(c.DMatch) == 16 and c.DMatch.distance.offset == 12
     assert ctypes.sizeof(c.Score) == 8
     p = c.default_params()
-    assert (p.ratio, p.dist_floor, p.min_matches, p.min_gap, p.sim_threshold) == (2, 0, 50, 30, 0.15)
+    assert (p.ratio, p.dist_floor, p.min_matches, p.min_gap, p.sim_threshold, p.cross_check) == (2, 0, 50, 30, 0.15, 0)
+    assert ctypes.sizeof(c.Params) == 32
 
 
 def test_backend_name_and_loop_test_need_no_device(pkg):
