@@ -3,16 +3,30 @@
 // include/lcm.h, so that a program written against that header links against liblcm_hip.so unchanged.
 //
 // NOT built in this repository's image (no OpenCV here).  Build where OpenCV 4.x is installed:
-//   g++ -std=c++17 -I<reference>/include -I<this repo>/include $(pkg-config --cflags opencv4) \
-//       -c adapters/opencv/loop_closing.cpp
+//   g++ -std=c++17 -I<reference>/include -I<this repo>/include $(pkg-config --cflags opencv4)
+//       -c adapters/opencv/loop_closing.cpp                                        (one command line)
 //   ... link with -L<this repo>/slam-loop-closing_amd/lib -llcm_hip $(pkg-config --libs opencv4)
 //
 // The reference ships no src/loop_closing.cpp, so this file is written from the header and README only.  The header's
 // private members cannot change ("drop-in"), so the GPU handle lives in a side table keyed by `this`; the
 // cv::Ptr<cv::BFMatcher> matcher_ member (hpp:73) stays empty.  estimatePose / triangulatePoints / visualizeMatches
 // are outside the Hamming path and are not defined here.
+//
+// Limitation of a drop-in for THIS header: it declares no destructor, so nothing tells the adapter when an object
+// dies.  The constructor therefore always starts from a fresh matcher (an object built at a recycled address never
+// inherits its predecessor's device database), and a program that creates many systems should call
+// loop_closing::lcm_release(&system) before the object goes away; otherwise the last handle of each address stays
+// allocated until exit.
+//
+// In this repository the file is only SYNTAX-checked (tests/test_adapter_syntax.py: g++ -fsyntax-only against the
+// reference's real header and declaration stubs for the cv:: names) — hygiene, not parity.
 #include "loop_closing.hpp"   // the reference's header
 
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
 #include <fstream>
 #include <mutex>
 #include <stdexcept>
@@ -28,10 +42,14 @@ std::unordered_map<const LoopClosingSystem*, lcm_handle*> g_handles;
 
 [[noreturn]] void raise(const char* what) { throw std::runtime_error(std::string(what) + ": " + lcm_last_error()); }
 
-lcm_handle* handle_for(const LoopClosingSystem* self, double loop_threshold, int min_loop_gap) {
+lcm_handle* handle_for(const LoopClosingSystem* self, double loop_threshold, int min_loop_gap, bool fresh = false) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_handles.find(self);
-    if (it != g_handles.end()) return it->second;
+    if (it != g_handles.end()) {
+        if (!fresh) return it->second;
+        lcm_destroy(it->second);          // a new object at a recycled address: drop the old object's database
+        g_handles.erase(it);
+    }
     lcm_params p;
     lcm_params_default(&p);
     p.sim_threshold = loop_threshold;
@@ -52,11 +70,20 @@ const uint8_t* rows_of(const cv::Mat& d, cv::Mat& keep) {
 
 }  // namespace
 
+// Explicit release hook (the reference header has no destructor to do it): frees the object's matcher and device database.
+void lcm_release(const LoopClosingSystem* self) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_handles.find(self);
+    if (it == g_handles.end()) return;
+    lcm_destroy(it->second);
+    g_handles.erase(it);
+}
+
 LoopClosingSystem::LoopClosingSystem(double loop_threshold, int min_loop_gap)
     : loop_threshold_(loop_threshold), min_loop_gap_(min_loop_gap) {
     feature_detector_ = cv::ORB::create(2000);   // README.md:114
     K_ = (cv::Mat_<double>(3, 3) << 800, 0, 640, 0, 800, 360, 0, 0, 1);   // README.md:131
-    handle_for(this, loop_threshold_, min_loop_gap_);
+    handle_for(this, loop_threshold_, min_loop_gap_, /*fresh*/ true);
 }
 
 void LoopClosingSystem::detectFeatures(Frame& frame) {
@@ -112,6 +139,8 @@ void LoopClosingSystem::processFrame(const cv::Mat& image, int frame_id) {
 }
 
 void LoopClosingSystem::saveResults(const std::string& output_dir) {
+    if (mkdir(output_dir.c_str(), 0777) != 0 && errno != EEXIST)
+        throw std::runtime_error("saveResults: cannot create " + output_dir + ": " + strerror(errno));
     std::ofstream os(output_dir + "/loop_closures.txt");
     if (!os) throw std::runtime_error("saveResults: cannot open " + output_dir + "/loop_closures.txt");
     os << "=== Processing Complete ===\n"

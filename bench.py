@@ -68,7 +68,7 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline_sample(entry, pkg, fs, gap, offs, got, seconds, threads, shard=None):
+def cpu_baseline_sample(entry, pkg, fs, gap, offs, got, seconds, threads, shard=None, got_idx=None):
     """The oracle's tuned CPU path on a random sample of the workload's eligible pairs sized for ~`seconds` of CPU work;
     `got` (optional) = the GPU's records in single-device order, compared on the same pairs (0 mismatches required).
     shard = (rank, world): sample only pairs whose stored frame that rank owns; `got`/`offs` are then that shard's."""
@@ -96,6 +96,15 @@ def cpu_baseline_sample(entry, pkg, fs, gap, offs, got, seconds, threads, shard=
         local_t = ts[:n_s] if shard is None else (ts[:n_s] - shard[0]) // shard[1]
         idx = offs[qs[:n_s]].astype(np.int64) + local_t
         mismatch = int(np.sum(got[idx] != cs))
+        if got_idx is not None:
+            # match INDICES too: the per-pair checksum of the good matches' train indices (a subsample: the oracle's
+            # index-tracking pass is run outside the timed sample)
+            k = min(n_s, 4096)
+            _, isum = oracle.fast_score_pairs_idx(fs.rows, fs.counts, qs[:k], ts[:k], op, threads)
+            bad = int(np.sum(got_idx[idx[:k]] != isum))
+            out["gpu_vs_cpu_index_checksum_mismatches"] = bad
+            out["index_checksums_compared"] = int(k)
+            mismatch += bad
         out["gpu_vs_cpu_sample_mismatches"] = mismatch
         if mismatch:
             print(f"PARITY FAILURE: {mismatch} of {n_s} sampled pairs differ from the CPU oracle", file=sys.stderr)
@@ -273,7 +282,9 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override the frame count")
     ap.add_argument("--desc", type=int, default=0, help="override descriptors per frame")
     ap.add_argument("--gap", type=int, default=30)
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (A/B measurement)")
+    ap.add_argument("--variant", type=int, default=1, help="1 (default): the ARGMIN kernel through lcm_all_vs_all_argmin — "
+                    "per-query min AND first-minimum train index, per-pair index checksum written; 0: distance-only kernel; "
+                    "2 / 3: the train-row-per-lane mapping (A/B measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget; 0 disables")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores this process may use")
     ap.add_argument("--mode", default="batch", help="batch (default: one all-vs-all pass per step) | stream (online: "
@@ -356,7 +367,8 @@ def main():
     p = pkg.default_params()
     p.min_gap = args.gap
     m = pkg.Matcher(p, device=local_rank, stream=stream.cuda_stream)
-    m.set_kernel_variant(args.variant)
+    argmin_api = (args.variant == 1)                 # headline: north_star's "per-query min/argmin + match count"
+    m.set_kernel_variant(0 if argmin_api else args.variant)
     owned = pkg.sharding.owned_positions(n_frames, rank, world)
     m.reserve(len(owned), n_desc)
     frame_bytes = fs.stride_rows * 32
@@ -370,6 +382,7 @@ def main():
                       q_stride_rows=fs.stride_rows)
         n_local, offs = m.all_vs_all_plan(**q_args)
     scores = torch.zeros(max(n_local, 1), dtype=torch.int64, device=dev)     # 8-byte lcm_score records
+    idx_sums = torch.zeros(max(n_local, 1), dtype=torch.int32, device=dev)   # argmin kernel: per-pair index checksum
     cdev = dev if args.backend == "nccl" else torch.device("cpu")
     if multi:
         n_t = torch.tensor([n_local], dtype=torch.int64, device=cdev)
@@ -385,14 +398,20 @@ def main():
     fused_out = {}
     fused_buf = np.zeros(max(n_local, 1), pkg.capi.CANDIDATE_DTYPE) if fused else None     # worst case: every pair
 
+    def search(d_scores_ptr, n):
+        if argmin_api:
+            m.all_vs_all_argmin(d_scores_ptr, n, idx_sums.data_ptr(), **q_args)
+        else:
+            m.all_vs_all(d_scores_ptr, n, **q_args)
+
     def step():
         if fused:
             # lcm_all_vs_all_loops: score kernel -> scores stay in HBM -> k_loop_test -> compacted candidates -> host
             fused_out["cands"], fused_out["pairs"] = m.all_vs_all_loops(out=fused_buf, **q_args)
         elif not multi:
-            m.all_vs_all(scores.data_ptr(), n_local, **q_args)
+            search(scores.data_ptr(), n_local)
         else:
-            m.all_vs_all(send.data_ptr(), cap, **q_args)          # kernel writes straight into the send buffer
+            search(send.data_ptr(), cap)                          # kernel writes straight into the send buffer
             if args.backend == "nccl":
                 dist.all_gather_into_tensor(recv, send)           # RCCL over xGMI: per-shard score records
             else:
@@ -424,22 +443,24 @@ def main():
     # a few more individually timed launches for a stable per-launch duration (outside the timed region)
     loop_test_ms = info.aux_kernel_ms if fused else None
     for _ in range(min(3, max(args.steps - 1, 0)) if not fused else 0):
-        m.all_vs_all((send if multi else scores).data_ptr(), cap if multi else n_local, **q_args)
+        search((send if multi else scores).data_ptr(), cap if multi else n_local)
         kernel_ms.append(m.launch_info().kernel_ms)
     kern_ms = float(np.mean(kernel_ms))
 
     local_dist = int(info.distances)
-    # the same workload through the (dist, idx)-key kernel the pair mode uses: reported beside the headline number
-    argmin_ms = None
-    if args.variant == 0 and not fused:
-        m.set_kernel_variant(1)
+    # the same workload through the OTHER row-per-lane kernel, reported beside the headline number: distance-only when the
+    # headline is the argmin kernel, and the other way round
+    other_ms = None
+    if args.variant in (0, 1) and not fused:
         ms = []
         for _ in range(2):
-            m.all_vs_all((send if multi else scores).data_ptr(), cap if multi else n_local, **q_args)
+            if argmin_api:
+                m.all_vs_all((send if multi else scores).data_ptr(), cap if multi else n_local, **q_args)
+            else:
+                m.all_vs_all_argmin((send if multi else scores).data_ptr(), cap if multi else n_local, idx_sums.data_ptr(), **q_args)
             ms.append(m.launch_info().kernel_ms)
-        argmin_ms = float(np.mean(ms))
-        m.set_kernel_variant(0)
-        m.all_vs_all((send if multi else scores).data_ptr(), cap if multi else n_local, **q_args)
+        other_ms = float(np.mean(ms))
+        search((send if multi else scores).data_ptr(), cap if multi else n_local)      # leave the headline's outputs behind
         m.sync()
 
     tot = torch.tensor([local_dist, int(info.pairs), int(info.algo_bytes)], dtype=torch.int64, device=cdev)
@@ -479,7 +500,9 @@ def main():
     if rank == 0 and not multi and args.cpu_seconds > 0:
         torch.cuda.synchronize(dev)
         got = fused_scores if fused else scores.cpu().numpy().view(pkg.capi.SCORE_DTYPE)[:n_local]
-        cpu = cpu_baseline_sample(entry, pkg, fs, args.gap, offs, got, args.cpu_seconds, args.cpu_threads or host_cores())
+        got_idx = idx_sums.cpu().numpy().view(np.uint32)[:n_local] if (argmin_api and not fused) else None
+        cpu = cpu_baseline_sample(entry, pkg, fs, args.gap, offs, got, args.cpu_seconds, args.cpu_threads or host_cores(),
+                                  got_idx=got_idx)
 
     if rank == 0:
         traffic = None
@@ -501,13 +524,17 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl_desc, "frames": n_frames, "descriptors_per_frame": n_desc, "min_gap": args.gap,
                        "pairs_per_step": total_pairs, "distances_per_step": total_dist, "seed": seed,
-                       "sharding": "cyclic by frame" if world > 1 else "none", "kernel_variant": args.variant},
+                       "sharding": "cyclic by frame" if world > 1 else "none", "kernel_variant": args.variant,
+                       "api": "lcm_all_vs_all_loops" if fused else ("lcm_all_vs_all_argmin" if argmin_api else "lcm_all_vs_all"),
+                       "outputs": "score record (good-match count, min distance) per pair" +
+                                  (" + checksum of the good matches' first-minimum train indices per pair" if argmin_api and not fused else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": None if traffic is None else
                          "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command "
                          "(gfx950 corrections applied), NOT measured in this run",
-                         "kernel": "k_score_rowlane", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "kernel": "k_score_rowlane<256,8,1,false> (argmin)" if argmin_api and not fused else "k_score_rowlane<256,8,0,false>",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "note": "this path is VALU-bound by ~200x (0.016 algorithmic bytes per distance); see roofline_valu"},
             "roofline_valu": {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
                               "frac": kern_rate / VALU_PEAK_DIST_PER_S,
@@ -516,10 +543,12 @@ def main():
                                                "(v_bcnt_u32_b32 measures 4.19: tools/valu_class.hip)",
                               "model": "8 v_xor_b32 (2 cyc) + 8 v_bcnt_u32_b32 (4 cyc) per 64 distances per SIMD, "
                                        "1024 SIMDs @ 2.4 GHz"},
-            "argmin_kernel": None if argmin_ms is None else {
-                "what": "same workload, kernel variant that also tracks the train index of every minimum "
-                        "(the (dist, idx)-key kernel behind lcm_match_pair / matchFeatures)",
-                "kernel_ms": argmin_ms, "distances_per_s": local_dist / (argmin_ms * 1e-3)},
+            ("distance_only_kernel" if argmin_api else "argmin_kernel"): None if other_ms is None else {
+                "what": ("same workload through lcm_all_vs_all, kernel variant 0: best distance per query row only (what a "
+                         "LoopCandidate needs; no train index)" if argmin_api else
+                         "same workload through lcm_all_vs_all_argmin: per-query min AND first-minimum train index "
+                         "(16-row group keys in lane-private LDS + re-scan), per-pair index checksum written"),
+                "kernel_ms": other_ms, "distances_per_s": local_dist / (other_ms * 1e-3)},
             "cpu_baseline": cpu,
         }
         if multi:
