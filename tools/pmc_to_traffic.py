@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, as MI355X_MICROARCH.md prescribes) of
 `bench.py --steps 1 --warmup 0 --cpu-seconds 0` into profiles/hbm_traffic.json, which bench.py reports as
-roofline.traffic.  Usage: pmc_to_traffic.py <fetch_csv> <write_csv> <out_json> [frames n_gpus workload]"""
+roofline.traffic.  Usage: pmc_to_traffic.py <fetch_csv> <write_csv> <out_json> [frames n_gpus workload kernel_substr]"""
 import csv
 import json
 import sys
 
 
-def kernel_sum(path, counter, kernel_substr="k_score_rowlane<256, 8, false, false>"):   # the loop-search kernel only
+KERNEL = sys.argv[7] if len(sys.argv) > 7 else "k_score_rowlane<256, 8, 1, false>"      # the headline (argmin) kernel
+
+
+def kernel_sum(path, counter, kernel_substr=KERNEL):   # the loop-search kernel only
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
         if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
@@ -21,7 +24,7 @@ write_kb, nw = kernel_sum(sys.argv[2], "WRITE_SIZE")
 launches = max(nf, 1)
 out = {
     "workload": sys.argv[6] if len(sys.argv) > 6 else "cfg2", "frames": int(sys.argv[4]) if len(sys.argv) > 4 else 1000,
-    "n_gpus": int(sys.argv[5]) if len(sys.argv) > 5 else 1, "kernel": "k_score_rowlane", "launches_profiled": launches,
+    "n_gpus": int(sys.argv[5]) if len(sys.argv) > 5 else 1, "kernel": KERNEL, "launches_profiled": launches,
     "FETCH_SIZE_KB_per_launch": fetch_kb / launches, "WRITE_SIZE_KB_per_launch": write_kb / max(nw, 1),
     # FETCH_SIZE = TCC_EA0_RDREQ x 64 B / 1024.  This kernel's reads are 64-byte scalar loads (s_load_dwordx16) plus a
     # few 16-byte vector loads, not the 16 B/lane wide streaming pattern for which the guide measured the counter at
