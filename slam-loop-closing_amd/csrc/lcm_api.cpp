@@ -220,6 +220,7 @@ void lcm_destroy(lcm_handle* h) {
     if (h->h_pair_stage) (void)hipHostFree(h->h_pair_stage);
     if (h->h_final_keys) (void)hipHostFree(h->h_final_keys);
     (void)hipFree(h->d_pair_stage); (void)hipFree(h->d_xq);
+    (void)hipFree(h->d_pm1); (void)hipFree(h->d_qpm1); (void)hipFree(h->d_mdist); (void)hipFree(h->d_mitems); (void)hipFree(h->d_mmeta);
     if (h->db_ready) (void)hipEventDestroy(h->db_ready);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -257,7 +258,7 @@ int lcm_sync(lcm_handle* h) {
 
 int lcm_set_kernel_variant(lcm_handle* h, int variant) {
     if (!h) return fail(LCM_ERR_INVALID_ARG, "NULL handle");
-    if (variant < 0 || variant > 3) return fail(LCM_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
+    if (variant < 0 || variant > 4) return fail(LCM_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
     h->variant = variant;
     return LCM_OK;
 }
@@ -857,6 +858,120 @@ static int cross_score_prefixes(lcm_handle* h, const uint8_t* d_qbase, const uin
     return LCM_OK;
 }
 
+// OPT-IN variant 4: the bulk search on the matrix cores (lcm_mfma.hip).  Same records as variants 0 / 1, bit for bit.
+// qbase / q_pitch_rows / q_frame_of describe the query set's packed rows (the arena itself in self mode); nqv[c] and
+// offsets come from the plan.  Work goes out in chunks of <= 262,144 pairs (2 GiB of per-row distances).
+static int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int32_t* d_q_counts, uint32_t q_pitch_rows,
+                     const uint32_t* q_frame_of, const int* nqv, int n_q, const std::vector<size_t>& offsets, lcm_score* d_scores) {
+    const uint32_t db_tiles = (uint32_t)((h->stride_rows + 31) / 32);
+    const size_t n_db = h->frames.size();
+    // ---- operand images
+    uint64_t stamp = mix(mix(mix(mix(0x77, h->db_generation), (uint64_t)n_db), (uint64_t)h->stride_rows), (uint64_t)(uintptr_t)h->d_rows);
+    if (!h->frames.empty()) stamp = mix(stamp, (uint64_t)h->frames.back().id);
+    int rc = ensure_dev(h->d_pm1, h->d_pm1_bytes, std::max<size_t>(n_db, 1) * db_tiles * lcm::PM1_TILE_BYTES);
+    if (rc) return rc;
+    if (h->pm1_stamp != stamp) {
+        hipError_t e = lcm::launch_expand_pm1((const uint32_t*)h->d_rows, h->d_counts, (uint32_t)h->stride_rows * LCM_DESC_WORDS,
+                                              (uint32_t)n_db, db_tiles, h->d_pm1, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "expand kernel launch failed: %s", hipGetErrorString(e));
+        h->pm1_stamp = stamp;
+    }
+    const uint8_t* q_pm1 = h->d_pm1;
+    uint32_t q_tiles = db_tiles;
+    const int32_t* q_counts_dev = h->d_counts;
+    if (!self) {
+        uint32_t n_slots = 0;
+        for (int c = 0; c < n_q; ++c) n_slots = std::max(n_slots, (q_frame_of ? q_frame_of[c] : (uint32_t)c) + 1);
+        q_tiles = (q_pitch_rows + 31) / 32;
+        rc = ensure_dev(h->d_qpm1, h->d_qpm1_bytes, (size_t)n_slots * q_tiles * lcm::PM1_TILE_BYTES); if (rc) return rc;
+        hipError_t e = lcm::launch_expand_pm1((const uint32_t*)q_rows, d_q_counts, q_pitch_rows * LCM_DESC_WORDS, n_slots, q_tiles, h->d_qpm1, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "expand kernel launch failed: %s", hipGetErrorString(e));
+        q_pm1 = h->d_qpm1;
+        q_counts_dev = d_q_counts;
+    }
+    // ---- per-query metadata for the fold: offsets | nq
+    std::vector<uint32_t> meta((size_t)n_q * 2 + 1);
+    for (int c = 0; c <= n_q; ++c) meta[(size_t)c] = (uint32_t)offsets[(size_t)c];
+    for (int c = 0; c < n_q; ++c) meta[(size_t)n_q + 1 + (size_t)c] = (uint32_t)nqv[c];
+    rc = ensure_dev(h->d_mmeta, h->d_mmeta_n, meta.size()); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_mmeta, meta.data(), sizeof(uint32_t) * meta.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    constexpr size_t CHUNK_PAIRS = 262144;
+    constexpr uint32_t SPI = 4;                          // stored frames per work item
+    uint32_t launches = 0, biggest = 0;
+    uint64_t dist = 0, bytes = 0;
+    std::vector<lcm::MfmaItem> items;
+    int c0 = 0;
+    bool first = true;
+    while (c0 < n_q) {
+        int c1 = c0;
+        size_t pairs = 0;
+        while (c1 < n_q && (pairs == 0 || pairs + (offsets[(size_t)c1 + 1] - offsets[(size_t)c1]) <= CHUNK_PAIRS)) { pairs += offsets[(size_t)c1 + 1] - offsets[(size_t)c1]; ++c1; }
+        if (pairs > 0) {
+            // runs of SPI stored frames per query frame; the 8 query chunks of 8 consecutive runs are interleaved so that
+            // workgroup b and b + 8 (same XCD under round-robin placement: speed only) stream the same stored frames
+            struct Run { uint32_t qf, n_chunks, slot_begin, n_slots, out; };
+            std::vector<Run> runs;
+            for (int c = c1 - 1; c >= c0; --c) {                 // heaviest query frames first
+                const uint32_t e = (uint32_t)(offsets[(size_t)c + 1] - offsets[(size_t)c]);
+                const uint32_t nch = (uint32_t)((nqv[c] + 255) / 256);
+                for (uint32_t b = 0; b < e && nch > 0; b += SPI)
+                    runs.push_back({q_frame_of ? q_frame_of[c] : (uint32_t)c, nch, b, std::min(SPI, e - b), (uint32_t)offsets[(size_t)c] + b});
+                if (nch == 0) {                                  // an empty query frame: its records are all "empty pair"
+                    // (the fold kernel writes them from nq = 0; no scoring work)
+                }
+            }
+            items.clear();
+            for (size_t g = 0; g < runs.size(); g += 8) {
+                const size_t nr = std::min<size_t>(8, runs.size() - g);
+                uint32_t max_ch = 0;
+                for (size_t k = 0; k < nr; ++k) max_ch = std::max(max_ch, runs[g + k].n_chunks);
+                for (uint32_t qc = 0; qc < max_ch; ++qc)
+                    for (size_t k = 0; k < 8; ++k) {
+                        if (k < nr && qc < runs[g + k].n_chunks) items.push_back({runs[g + k].qf, qc, runs[g + k].slot_begin, runs[g + k].n_slots, runs[g + k].out});
+                        else items.push_back({0, 0, 0, 0, 0});  // keeps workgroup index mod 8 aligned with the run
+                    }
+            }
+            rc = ensure_dev(h->d_mdist, h->d_mdist_n, pairs * (size_t)lcm::MAX_FUSED_QUERY_ROWS); if (rc) return rc;
+            if (!first) HIP_TRY(hipStreamSynchronize(h->stream));                 // the previous chunk still reads its item list
+            rc = ensure_dev(h->d_mitems, h->d_mitems_bytes, items.size() * sizeof(lcm::MfmaItem)); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(h->d_mitems, items.data(), items.size() * sizeof(lcm::MfmaItem), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));                             // `items` is reused by the next chunk
+            lcm::MfmaArgs a{};
+            a.q_pm1 = q_pm1; a.q_tiles_per_frame = q_tiles; a.q_counts = q_counts_dev;
+            a.db_pm1 = h->d_pm1; a.db_tiles_per_frame = db_tiles; a.db_counts = h->d_counts;
+            a.items = reinterpret_cast<const lcm::MfmaItem*>(h->d_mitems);
+            a.dist = h->d_mdist; a.pair_base = (uint32_t)offsets[(size_t)c0];
+            hipError_t e = lcm::launch_score_mfma(a, (uint32_t)items.size(), h->stream);
+            if (e != hipSuccess) return fail(LCM_ERR_HIP, "MFMA kernel launch failed: %s", hipGetErrorString(e));
+            lcm::FinalizeBulkArgs f{};
+            f.dist = h->d_mdist; f.offsets = h->d_mmeta; f.nq = reinterpret_cast<const int32_t*>(h->d_mmeta + n_q + 1);
+            f.db_counts = h->d_counts; f.scores = d_scores; f.n_q = (uint32_t)n_q; f.pair_base = (uint32_t)offsets[(size_t)c0];
+            f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
+            e = lcm::launch_finalize_bulk(f, (uint32_t)pairs, h->stream);
+            if (e != hipSuccess) return fail(LCM_ERR_HIP, "fold kernel launch failed: %s", hipGetErrorString(e));
+            launches += 2; biggest = std::max(biggest, (uint32_t)items.size());
+            first = false;
+        }
+        c0 = c1;
+    }
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    // accounting: same algorithmic definition as the VALU path (packed rows: what the search has to read)
+    {
+        std::vector<uint64_t> pre(n_db + 1, 0);
+        for (size_t s2 = 0; s2 < n_db; ++s2) pre[s2 + 1] = pre[s2] + (uint64_t)h->frames[s2].n;
+        for (int c = 0; c < n_q; ++c) {
+            const size_t e = offsets[(size_t)c + 1] - offsets[(size_t)c];
+            if (e) { dist += (uint64_t)nqv[c] * pre[e]; bytes += pre[e] * 32 + (uint64_t)nqv[c] * 32 + 8ull * e; }
+        }
+    }
+    h->info_pending = true;
+    h->info.launches = launches; h->info.workgroups = biggest;
+    h->info.pairs = offsets[(size_t)n_q]; h->info.distances = dist; h->info.algo_bytes = bytes;
+    return LCM_OK;
+}
+
 // Enqueue (no host synchronisation) the scoring of ONE query frame — `nq` rows at device address d_q — against stored
 // slots [0, n_elig), and the download of the n_elig score records into the slot's pinned buffer.  Work items are
 // implicit (derived from blockIdx), so nothing but the query itself crosses PCIe.  Short databases use the split
@@ -1388,6 +1503,12 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
             ev[(size_t)c] = (int)(P.offsets[(size_t)c + 1] - P.offsets[(size_t)c]);
         }
         return cross_score_prefixes(h, qbase, row0.data(), nqv.data(), ev.data(), n_q_frames, (lcm_score*)d_scores, d_idx_sums);
+    }
+    if (h->variant == 4 && !d_idx_sums) {
+        std::vector<int> nqv((size_t)n_q_frames);
+        for (int c = 0; c < n_q_frames; ++c) nqv[(size_t)c] = self ? h->frames[(size_t)c].n : qc[(size_t)c];
+        return mfma_bulk(h, self, self ? h->d_rows : (const uint8_t*)d_query_rows, d_query_counts,
+                         (uint32_t)(self ? h->stride_rows : q_stride_rows), q_frame_of, nqv.data(), n_q_frames, P.offsets, (lcm_score*)d_scores);
     }
     lcm::ScoreArgs a{};
     a.q_rows = self ? (const uint32_t*)h->d_rows : (const uint32_t*)d_query_rows;

@@ -126,6 +126,12 @@ struct lcm_handle {
     uint8_t* d_pair_stage = nullptr; size_t d_pair_stage_bytes = 0;
     uint32_t* h_final_keys = nullptr; size_t h_final_keys_n = 0;      // pair mode: pinned landing zone of the folded keys
     uint8_t* d_xq = nullptr; size_t d_xq_bytes = 0;                   // cross_check: padded copy of an external query set
+    // opt-in MFMA variant (4): +1 / -1 int8 operand images of the database and of an external query set, scratch
+    uint8_t* d_pm1 = nullptr; size_t d_pm1_bytes = 0; uint64_t pm1_stamp = 0;
+    uint8_t* d_qpm1 = nullptr; size_t d_qpm1_bytes = 0;
+    uint32_t* d_mdist = nullptr; size_t d_mdist_n = 0;
+    uint8_t* d_mitems = nullptr; size_t d_mitems_bytes = 0;
+    uint32_t* d_mmeta = nullptr; size_t d_mmeta_n = 0;
     lcm_score* d_bulk_scores = nullptr; size_t d_bulk_scores_n = 0;   // lcm_all_vs_all_loops: scores stay on the device
     size_t bulk_scores_valid = 0;                                     // records of the last fused call still in there
     int32_t* d_meta = nullptr; size_t d_meta_n = 0;

@@ -148,6 +148,48 @@ hipError_t launch_cross_score(const CrossArgs& a, uint32_t n_pairs, hipStream_t 
 // copies of its row n - 1 (n = counts[f]; nothing is written for n == 0).  stride_rows >= round_up(max n, 4) + 4.
 hipError_t launch_pad_rows(uint32_t* rows, const int32_t* counts, uint32_t stride_rows, uint32_t n_frames, hipStream_t st);
 
+// ---- OPT-IN matrix-core variant (lcm_set_kernel_variant(4)) ---------------------------------------------------------
+// BASELINE.json's north_star rules MFMA out for the product path ("this path is integer bitwise work"), and variants
+// 0 / 1 honour that.  Variant 4 exists to MEASURE what the rule costs: the same exact integers from
+// v_mfma_i32_32x32x32_i8.  With every descriptor bit mapped to an int8 +1 / -1, <q, t> = 256 - 2 * hamming(q, t), so
+// min distance = max dot product, exactly, in int32.
+//
+// Expanded operand image ("pm1"): per frame, per tile of 32 rows, per k-step of 32 bits: 64 lanes x 16 bytes =
+// 1 KiB, lane (r = lane & 31, h = lane >> 5) holding bits [32 ks + 16 h, +16) of row 32 tile + r as 16 int8 — exactly
+// one MFMA operand fragment per lane, so a wave's fragment load is one coalesced, conflict-free 1 KiB block.  Rows
+// past a frame's end repeat its last row (cannot beat it).  8 KiB per tile = 8x the packed bytes.
+constexpr int PM1_TILE_BYTES = 8192;
+hipError_t launch_expand_pm1(const uint32_t* rows, const int32_t* counts, uint32_t stride_words, uint32_t n_frames,
+                             uint32_t tiles_per_frame, uint8_t* pm1, hipStream_t st);
+
+// One workgroup (4 waves) = 256 query rows (chunk q_chunk of query frame q_frame) against stored slots
+// [slot_begin, slot_begin + n_slots): wave w keeps query tiles 2w, 2w+1 of the chunk in registers as B operands (64
+// VGPRs), the stored frame's tiles stream through LDS as A operands (double-buffered, shared by the 4 waves), 16 MFMAs
+// per tile per wave, running max per query in registers.  Output: best DISTANCE per (pair, query row) -> dist; the
+// per-pair records come from launch_finalize_bulk (min-of-mins, ratio filter, count).
+struct MfmaItem { uint32_t q_frame, q_chunk, slot_begin, n_slots, out_offset; };
+struct MfmaArgs {
+    const uint8_t*  q_pm1;  uint32_t q_tiles_per_frame;  const int32_t* q_counts;    // query frames (expanded)
+    const uint8_t*  db_pm1; uint32_t db_tiles_per_frame; const int32_t* db_counts;   // stored frames (expanded)
+    const MfmaItem* items;
+    uint32_t*       dist;          // dist[(out_offset + s - pair_base) * 2048 + query row]
+    uint32_t        pair_base;
+};
+hipError_t launch_score_mfma(const MfmaArgs& a, uint32_t n_items, hipStream_t st);
+
+// Pair p (global index, pair_base <= p < pair_base + n_pairs) belongs to query c = last c with offsets[c] <= p and is
+// stored slot p - offsets[c]; folds dist[(p - pair_base) * 2048 + r], r < nq[c], into the pair's score record.
+struct FinalizeBulkArgs {
+    const uint32_t* dist;
+    const uint32_t* offsets;       // n_q + 1
+    const int32_t*  nq;            // n_q query row counts
+    const int32_t*  db_counts;
+    void*           scores;        // records at scores[p]
+    uint32_t        n_q, pair_base;
+    int32_t         ratio, dist_floor;
+};
+hipError_t launch_finalize_bulk(const FinalizeBulkArgs& a, uint32_t n_pairs, hipStream_t st);
+
 // Multi-GPU merge (lcm_group_*): the W per-shard score arrays, gathered back to back on one device, are un-permuted
 // into the single-device (query ascending, stored ascending) order.  Shard r's records are in (query ascending, owned
 // stored ascending) order; query c's k-th record of shard r is stored position r + k * W, so it lands at

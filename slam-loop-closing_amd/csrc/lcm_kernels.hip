@@ -779,6 +779,7 @@ hipError_t launch_merge_shards(const MergeArgs& a, hipStream_t st) {
 // All selectable so they can be measured on the same workload (bench.py --variant N).
 hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
                         hipStream_t st) {
+    if (variant == 4) variant = 0;        // the matrix-core variant covers the bulk search only (lcm_api.cpp: mfma_bulk)
     if (variant >= 2 && !a.pair_items && max_query_rows <= 2048 && a.db_stride_words != 0 && a.db_stride_words <= 2048 * 8) {
         if (n_items == 0) return hipSuccess;
         const bool argmin = write_keys || variant == 3;
@@ -787,6 +788,7 @@ hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows
         else hipLaunchKernelGGL((k_score_trainlane<false, false>), dim3(n_items), dim3(256), 0, st, a);
         return hipGetLastError();
     }
+    // variant 4 (matrix cores) covers the bulk search only (lcm_api.cpp: mfma_bulk); everything else runs variant 0
     const bool argmin = write_keys || variant == 1 || variant == 3;
     if (max_query_rows <= 512) return launch_rowlane<64, 8>(a, n_items, write_keys, argmin, st);
     if (max_query_rows <= 1024) return launch_rowlane<128, 8>(a, n_items, write_keys, argmin, st);

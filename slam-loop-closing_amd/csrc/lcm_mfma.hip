@@ -1,0 +1,165 @@
+// lcm_mfma.hip — OPT-IN matrix-core variant of the loop search (lcm_set_kernel_variant(4)); see lcm_kernels.h.
+//
+// Not the product default: BASELINE.json's north_star asks for XOR + popcount on the vector ALU ("no MFMA"), which
+// is what variants 0 / 1 in lcm_kernels.hip do.  This file turns DESIGN.md's estimate of what that rule costs into a
+// measurement, bit-exact against the same tests.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lcm_kernels.h"
+
+namespace lcm {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ---- bits -> +1 / -1 int8 operand image -----------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_expand_pm1(const uint32_t* rows, const int32_t* counts, uint32_t stride_words,
+                                                    uint32_t tiles_per_frame, uint8_t* pm1) {
+    const uint32_t tile = blockIdx.x, frame = blockIdx.y;
+    const int n = counts[frame];
+    if ((int)(tile * 32) >= n) return;                          // the kernel never reads tiles past a frame's rows
+    const uint32_t ks = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t r = min(tile * 32 + (lane & 31), (uint32_t)(n - 1));       // pad rows repeat the last row
+    const uint32_t h = lane >> 5;
+    const uint32_t word = rows[(size_t)frame * stride_words + (size_t)r * 8 + ks];          // bits [32 ks, 32 ks + 32)
+    const uint32_t bits = (word >> (16 * h)) & 0xFFFFu;
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v |= (((bits >> (4 * i + b)) & 1u) ? 0x01u : 0xFFu) << (8 * b);
+        o[i] = v;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(pm1 + ((size_t)frame * tiles_per_frame + tile) * PM1_TILE_BYTES) + ks * 64 + lane;
+    *dst = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+hipError_t launch_expand_pm1(const uint32_t* rows, const int32_t* counts, uint32_t stride_words, uint32_t n_frames,
+                             uint32_t tiles_per_frame, uint8_t* pm1, hipStream_t st) {
+    if (n_frames == 0 || tiles_per_frame == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_expand_pm1, dim3(tiles_per_frame, n_frames), dim3(512), 0, st, rows, counts, stride_words, tiles_per_frame, pm1);
+    return hipGetLastError();
+}
+
+// ---- the MFMA scoring kernel -----------------------------------------------------------------------------------------
+__device__ __forceinline__ int max16(const v16i& c) {
+    int m = max(max(c[0], c[1]), c[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) m = max(max(m, c[i]), c[i + 1]);
+    return max(m, c[15]);
+}
+
+__global__ __launch_bounds__(256, 4) void k_score_mfma(MfmaArgs a) {
+    __shared__ uint4 atile[2][512];                             // two 8 KiB stored-frame tiles (A operands)
+    const MfmaItem it = a.items[blockIdx.x];
+    if (it.n_slots == 0) return;                                // padding item of the XCD-interleaved order
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = a.q_counts[it.q_frame];
+    const uint32_t qt0 = it.q_chunk * 8 + (uint32_t)wave * 2;   // this wave's two query tiles
+    const uint32_t nq_tiles = (uint32_t)(nq + 31) / 32;
+
+    // B operands: the wave's 2 query tiles x 8 k-steps, resident for the whole item (tiles past the frame: zeros)
+    v4i b0[8], b1[8];
+    {
+        const uint4* qb = reinterpret_cast<const uint4*>(a.q_pm1 + ((size_t)it.q_frame * a.q_tiles_per_frame + qt0) * PM1_TILE_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            uint4 x = make_uint4(0, 0, 0, 0), y = make_uint4(0, 0, 0, 0);
+            if (qt0 < nq_tiles) x = qb[ks * 64 + lane];
+            if (qt0 + 1 < nq_tiles) y = qb[512 + ks * 64 + lane];
+            b0[ks] = v4i{(int)x.x, (int)x.y, (int)x.z, (int)x.w};
+            b1[ks] = v4i{(int)y.x, (int)y.y, (int)y.z, (int)y.w};
+        }
+    }
+
+    for (uint32_t s = 0; s < it.n_slots; ++s) {
+        const uint32_t slot = it.slot_begin + s;
+        const int nt = a.db_counts[slot];
+        const uint32_t nt_tiles = (uint32_t)(nt + 31) / 32;
+        const uint4* tb = reinterpret_cast<const uint4*>(a.db_pm1 + (size_t)slot * a.db_tiles_per_frame * PM1_TILE_BYTES);
+        int best0 = -0x7FFFFFFF, best1 = -0x7FFFFFFF;
+        if (nt_tiles > 0) {
+            // stage tile 0, then: compute tile t from LDS while tile t + 1 travels global -> registers -> LDS
+            uint4 g0 = tb[tid], g1 = tb[256 + tid];
+            atile[0][tid] = g0; atile[0][256 + tid] = g1;
+            __syncthreads();
+            for (uint32_t t = 0; t < nt_tiles; ++t) {
+                const int cur = (int)(t & 1);
+                if (t + 1 < nt_tiles) { g0 = tb[(size_t)(t + 1) * 512 + tid]; g1 = tb[(size_t)(t + 1) * 512 + 256 + tid]; }
+                v16i acc0 = {0}, acc1 = {0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const uint4 x = atile[cur][ks * 64 + lane];
+                    const v4i av = v4i{(int)x.x, (int)x.y, (int)x.z, (int)x.w};
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0[ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1[ks], acc1, 0, 0, 0);
+                }
+                best0 = max(best0, max16(acc0));
+                best1 = max(best1, max16(acc1));
+                if (t + 1 < nt_tiles) { atile[cur ^ 1][tid] = g0; atile[cur ^ 1][256 + tid] = g1; }
+                __syncthreads();                                 // tile t + 1 visible; tile t's buffer free for t + 2
+            }
+        }
+        // a query column's 32 stored rows of a tile sit in 16 registers of lane l and 16 of lane l + 32
+        best0 = max(best0, __shfl_xor(best0, 32, 64));
+        best1 = max(best1, __shfl_xor(best1, 32, 64));
+        if (lane < 32) {
+            uint32_t* out = a.dist + (size_t)(it.out_offset + s - a.pair_base) * MAX_FUSED_QUERY_ROWS;
+            const uint32_t r0 = qt0 * 32 + (uint32_t)lane, r1 = r0 + 32;
+            // <q, t> = 256 - 2 d  =>  d = (256 - dot) / 2, exact
+            if (r0 < (uint32_t)nq) out[r0] = nt > 0 ? (uint32_t)(256 - best0) >> 1 : 0xFFFFFFFFu;
+            if (r1 < (uint32_t)nq) out[r1] = nt > 0 ? (uint32_t)(256 - best1) >> 1 : 0xFFFFFFFFu;
+        }
+    }
+}
+
+hipError_t launch_score_mfma(const MfmaArgs& a, uint32_t n_items, hipStream_t st) {
+    if (n_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_score_mfma, dim3(n_items), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---- per-pair fold of the best distances ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a) {
+    __shared__ uint32_t red_min, red_sum;
+    const int tid = threadIdx.x;
+    const uint32_t p = a.pair_base + blockIdx.x;
+    uint32_t lo = 0, hi = a.n_q;                                // last c with offsets[c] <= p
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.offsets[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int nq = a.nq[lo];
+    const uint32_t slot = p - a.offsets[lo];
+    if (tid == 0) { red_min = 0xFFFFFFFFu; red_sum = 0u; }
+    __syncthreads();
+    const uint32_t* d = a.dist + (size_t)blockIdx.x * MAX_FUSED_QUERY_ROWS;
+    uint32_t dmin = 0xFFFFFFFFu;
+    for (int r = tid; r < nq; r += 256) dmin = min(dmin, d[r]);
+    atomicMin(&red_min, dmin);
+    __syncthreads();
+    dmin = red_min;
+    const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
+    uint32_t cnt = 0;
+    for (int r = tid; r < nq; r += 256) cnt += d[r] <= thr ? 1u : 0u;
+    atomicAdd(&red_sum, cnt);
+    __syncthreads();
+    if (tid == 0) {
+        const int nt = a.db_counts[slot];
+        const bool empty = (nq <= 0) || (nt <= 0);
+        uint2 rec;
+        rec.x = empty ? 0u : red_sum;
+        rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
+        reinterpret_cast<uint2*>(a.scores)[p] = rec;
+    }
+}
+
+hipError_t launch_finalize_bulk(const FinalizeBulkArgs& a, uint32_t n_pairs, hipStream_t st) {
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize_bulk, dim3(n_pairs), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace lcm

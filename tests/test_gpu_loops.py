@@ -229,9 +229,10 @@ def test_snapshot_restore_round_trip(matcher, pkg, tmp_path):
         matcher.clear()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_every_kernel_variant_is_bit_exact(matcher, oracle, pkg, variant):
-    """0/1: row-per-lane (distances / keys); 2/3: north_star's train-row-per-lane mapping with LDS-staged queries."""
+    """0/1: row-per-lane (distances / argmin); 2/3: north_star's train-row-per-lane mapping with LDS-staged queries;
+    4: the opt-in matrix-core variant (v_mfma_i32_32x32x32_i8 over +1/-1 operands)."""
     fs = pkg.synth.make_frames(26, 700, seed=41, ragged=True, dup_frac=0.4)
     fs.counts[4] = 0
     fs.counts[9] = 1
@@ -520,4 +521,52 @@ def test_batched_match_lists_equal_match_features_per_pair(matcher, oracle, pkg)
             matcher.match_stored_batch([(int(fs.ids[20]), int(fs.ids[2]))], cap=3)
         assert e.value.code == -4
     finally:
+        matcher.clear()
+
+
+@pytest.mark.parametrize("n_frames,max_desc,gap,seed", [(30, 2000, 2, 3), (50, 700, 1, 4), (64, 90, 3, 5), (20, 1300, 2, 6)])
+def test_matrix_core_variant_is_bit_exact(matcher, oracle, pkg, n_frames, max_desc, gap, seed):
+    """lcm_set_kernel_variant(4): self and external query sets, ragged frames (row counts not multiples of 32 / 256),
+    an empty and a 1-row frame, exact duplicates (distance 0), and the fused loop test on top of it."""
+    fs = pkg.synth.make_frames(n_frames, max_desc, seed=seed, ragged=True, dup_frac=0.4)
+    fs.counts[4] = 0
+    fs.counts[9] = 1
+    fs.rows[7, :20] = fs.rows[3, :20]
+    matcher.set_params(min_gap=gap)
+    matcher.set_kernel_variant(4)
+    d_rows = matcher.dev_alloc(fs.rows.nbytes)
+    d_counts = matcher.dev_alloc(fs.counts.nbytes)
+    try:
+        fill(matcher, fs)
+        p = oracle.default_params(min_gap=gap)
+        want, woffs = fast_all_vs_all(oracle, fs, p)
+        got, offs = gpu_all_vs_all(matcher)
+        np.testing.assert_array_equal(offs.astype(np.int64), woffs)
+        np.testing.assert_array_equal(got, want)
+        matcher.dev_upload(d_rows, fs.rows); matcher.dev_upload(d_counts, fs.counts)
+        got2, _ = gpu_all_vs_all(matcher, q_ids=fs.ids, d_rows=d_rows, d_counts=d_counts, stride=fs.stride_rows)
+        np.testing.assert_array_equal(got2, want)
+        matcher.append(int(fs.ids[-1]) + 1, fs.frame(1))         # the operand image follows the database
+        got3, offs3 = gpu_all_vs_all(matcher)
+        np.testing.assert_array_equal(got3[: len(want)], want)
+        cands, npairs = matcher.all_vs_all_loops(cap=len(got3))
+        keep = []
+        ids3 = list(fs.ids) + [int(fs.ids[-1]) + 1]
+        cnt3 = list(fs.counts) + [int(fs.counts[1])]
+        for c in range(len(ids3)):
+            for k in range(int(offs3[c]), int(offs3[c + 1])):
+                t = k - int(offs3[c])
+                if oracle.loop_test(int(got3[k]["good_count"]), cnt3[c], cnt3[t], p)[0]:
+                    keep.append((ids3[c], ids3[t], int(got3[k]["good_count"])))
+        assert [(int(r["current_frame_id"]), int(r["matched_frame_id"]), int(r["num_matches"])) for r in cands] == keep
+        # online queries and the pair mode keep working (vector-ALU kernels) under variant 4
+        sc, _ = matcher.query_scores(fs.frame(n_frames - 1), int(fs.ids[-1]) + 50)
+        assert len(sc) == n_frames + 1
+        idx, d = matcher.match_pair(fs.frame(2), fs.frame(3))
+        oi, od = oracle.bf_match(fs.frame(2), fs.frame(3))
+        np.testing.assert_array_equal(idx, oi)
+    finally:
+        matcher.dev_free(d_rows); matcher.dev_free(d_counts)
+        matcher.set_kernel_variant(0)
+        matcher.set_params(min_gap=30)
         matcher.clear()
