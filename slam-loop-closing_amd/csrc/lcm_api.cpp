@@ -258,7 +258,7 @@ int lcm_sync(lcm_handle* h) {
 
 int lcm_set_kernel_variant(lcm_handle* h, int variant) {
     if (!h) return fail(LCM_ERR_INVALID_ARG, "NULL handle");
-    if (variant < 0 || variant > 4) return fail(LCM_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
+    if (variant < 0 || variant > 5) return fail(LCM_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
     h->variant = variant;
     return LCM_OK;
 }
@@ -860,19 +860,25 @@ static int cross_score_prefixes(lcm_handle* h, const uint8_t* d_qbase, const uin
 
 // OPT-IN variant 4: the bulk search on the matrix cores (lcm_mfma.hip).  Same records as variants 0 / 1, bit for bit.
 // qbase / q_pitch_rows / q_frame_of describe the query set's packed rows (the arena itself in self mode); nqv[c] and
-// offsets come from the plan.  Work goes out in chunks of <= 262,144 pairs (2 GiB of per-row distances).
+// offsets come from the plan.  Work goes out in chunks of <= 524,288 pairs (4 GiB of per-row distances).
 static int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int32_t* d_q_counts, uint32_t q_pitch_rows,
                      const uint32_t* q_frame_of, const int* nqv, int n_q, const std::vector<size_t>& offsets, lcm_score* d_scores) {
+    const bool fp4 = (h->variant == 5);                  // 4: int8 operands, 256 query rows per workgroup; 5: fp4, 512
+    const size_t tile_bytes = fp4 ? lcm::FP4_TILE_BYTES : lcm::PM1_TILE_BYTES;
+    const int wg_rows = fp4 ? 512 : 256;
+    auto expand = [&](const uint32_t* rows, const int32_t* counts, uint32_t stride_words, uint32_t n_frames, uint32_t tiles, uint8_t* img) {
+        return fp4 ? lcm::launch_expand_fp4(rows, counts, stride_words, n_frames, tiles, img, h->stream)
+                   : lcm::launch_expand_pm1(rows, counts, stride_words, n_frames, tiles, img, h->stream);
+    };
     const uint32_t db_tiles = (uint32_t)((h->stride_rows + 31) / 32);
     const size_t n_db = h->frames.size();
     // ---- operand images
-    uint64_t stamp = mix(mix(mix(mix(0x77, h->db_generation), (uint64_t)n_db), (uint64_t)h->stride_rows), (uint64_t)(uintptr_t)h->d_rows);
+    uint64_t stamp = mix(mix(mix(mix(0x77 + (fp4 ? 1 : 0), h->db_generation), (uint64_t)n_db), (uint64_t)h->stride_rows), (uint64_t)(uintptr_t)h->d_rows);
     if (!h->frames.empty()) stamp = mix(stamp, (uint64_t)h->frames.back().id);
-    int rc = ensure_dev(h->d_pm1, h->d_pm1_bytes, std::max<size_t>(n_db, 1) * db_tiles * lcm::PM1_TILE_BYTES);
+    int rc = ensure_dev(h->d_pm1, h->d_pm1_bytes, std::max<size_t>(n_db, 1) * db_tiles * tile_bytes);
     if (rc) return rc;
     if (h->pm1_stamp != stamp) {
-        hipError_t e = lcm::launch_expand_pm1((const uint32_t*)h->d_rows, h->d_counts, (uint32_t)h->stride_rows * LCM_DESC_WORDS,
-                                              (uint32_t)n_db, db_tiles, h->d_pm1, h->stream);
+        hipError_t e = expand((const uint32_t*)h->d_rows, h->d_counts, (uint32_t)h->stride_rows * LCM_DESC_WORDS, (uint32_t)n_db, db_tiles, h->d_pm1);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "expand kernel launch failed: %s", hipGetErrorString(e));
         h->pm1_stamp = stamp;
     }
@@ -883,8 +889,8 @@ static int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int3
         uint32_t n_slots = 0;
         for (int c = 0; c < n_q; ++c) n_slots = std::max(n_slots, (q_frame_of ? q_frame_of[c] : (uint32_t)c) + 1);
         q_tiles = (q_pitch_rows + 31) / 32;
-        rc = ensure_dev(h->d_qpm1, h->d_qpm1_bytes, (size_t)n_slots * q_tiles * lcm::PM1_TILE_BYTES); if (rc) return rc;
-        hipError_t e = lcm::launch_expand_pm1((const uint32_t*)q_rows, d_q_counts, q_pitch_rows * LCM_DESC_WORDS, n_slots, q_tiles, h->d_qpm1, h->stream);
+        rc = ensure_dev(h->d_qpm1, h->d_qpm1_bytes, (size_t)n_slots * q_tiles * tile_bytes); if (rc) return rc;
+        hipError_t e = expand((const uint32_t*)q_rows, d_q_counts, q_pitch_rows * LCM_DESC_WORDS, n_slots, q_tiles, h->d_qpm1);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "expand kernel launch failed: %s", hipGetErrorString(e));
         q_pm1 = h->d_qpm1;
         q_counts_dev = d_q_counts;
@@ -897,7 +903,7 @@ static int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int3
     HIP_TRY(hipMemcpyAsync(h->d_mmeta, meta.data(), sizeof(uint32_t) * meta.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-    constexpr size_t CHUNK_PAIRS = 262144;
+    constexpr size_t CHUNK_PAIRS = 524288;               // 4 GiB of per-row best distances per chunk
     constexpr uint32_t SPI = 4;                          // stored frames per work item
     uint32_t launches = 0, biggest = 0;
     uint64_t dist = 0, bytes = 0;
@@ -915,7 +921,7 @@ static int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int3
             std::vector<Run> runs;
             for (int c = c1 - 1; c >= c0; --c) {                 // heaviest query frames first
                 const uint32_t e = (uint32_t)(offsets[(size_t)c + 1] - offsets[(size_t)c]);
-                const uint32_t nch = (uint32_t)((nqv[c] + 255) / 256);
+                const uint32_t nch = (uint32_t)((nqv[c] + wg_rows - 1) / wg_rows);
                 for (uint32_t b = 0; b < e && nch > 0; b += SPI)
                     runs.push_back({q_frame_of ? q_frame_of[c] : (uint32_t)c, nch, b, std::min(SPI, e - b), (uint32_t)offsets[(size_t)c] + b});
                 if (nch == 0) {                                  // an empty query frame: its records are all "empty pair"
@@ -943,7 +949,8 @@ static int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int3
             a.db_pm1 = h->d_pm1; a.db_tiles_per_frame = db_tiles; a.db_counts = h->d_counts;
             a.items = reinterpret_cast<const lcm::MfmaItem*>(h->d_mitems);
             a.dist = h->d_mdist; a.pair_base = (uint32_t)offsets[(size_t)c0];
-            hipError_t e = lcm::launch_score_mfma(a, (uint32_t)items.size(), h->stream);
+            hipError_t e = fp4 ? lcm::launch_score_mfma_fp4(a, (uint32_t)items.size(), h->stream)
+                               : lcm::launch_score_mfma(a, (uint32_t)items.size(), h->stream);
             if (e != hipSuccess) return fail(LCM_ERR_HIP, "MFMA kernel launch failed: %s", hipGetErrorString(e));
             lcm::FinalizeBulkArgs f{};
             f.dist = h->d_mdist; f.offsets = h->d_mmeta; f.nq = reinterpret_cast<const int32_t*>(h->d_mmeta + n_q + 1);
@@ -1504,7 +1511,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
         }
         return cross_score_prefixes(h, qbase, row0.data(), nqv.data(), ev.data(), n_q_frames, (lcm_score*)d_scores, d_idx_sums);
     }
-    if (h->variant == 4 && !d_idx_sums) {
+    if ((h->variant == 4 || h->variant == 5) && !d_idx_sums) {
         std::vector<int> nqv((size_t)n_q_frames);
         for (int c = 0; c < n_q_frames; ++c) nqv[(size_t)c] = self ? h->frames[(size_t)c].n : qc[(size_t)c];
         return mfma_bulk(h, self, self ? h->d_rows : (const uint8_t*)d_query_rows, d_query_counts,

@@ -177,6 +177,13 @@ struct MfmaArgs {
 };
 hipError_t launch_score_mfma(const MfmaArgs& a, uint32_t n_items, hipStream_t st);
 
+// Variant 5: the same on v_mfma_scale_f32_32x32x64_f8f6f4 with fp4 operands (+1 = 0x2, -1 = 0xA, scales 1.0): 4 KiB
+// per tile of 32 rows (4 k-steps of 64 bits), one workgroup = 512 query rows (q_chunk counts 512-row chunks).
+constexpr int FP4_TILE_BYTES = 4096;
+hipError_t launch_expand_fp4(const uint32_t* rows, const int32_t* counts, uint32_t stride_words, uint32_t n_frames,
+                             uint32_t tiles_per_frame, uint8_t* img, hipStream_t st);
+hipError_t launch_score_mfma_fp4(const MfmaArgs& a, uint32_t n_items, hipStream_t st);
+
 // Pair p (global index, pair_base <= p < pair_base + n_pairs) belongs to query c = last c with offsets[c] <= p and is
 // stored slot p - offsets[c]; folds dist[(p - pair_base) * 2048 + r], r < nq[c], into the pair's score record.
 struct FinalizeBulkArgs {

@@ -779,7 +779,7 @@ hipError_t launch_merge_shards(const MergeArgs& a, hipStream_t st) {
 // All selectable so they can be measured on the same workload (bench.py --variant N).
 hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
                         hipStream_t st) {
-    if (variant == 4) variant = 0;        // the matrix-core variant covers the bulk search only (lcm_api.cpp: mfma_bulk)
+    if (variant >= 4) variant = 0;        // the matrix-core variants cover the bulk search only (lcm_api.cpp: mfma_bulk)
     if (variant >= 2 && !a.pair_items && max_query_rows <= 2048 && a.db_stride_words != 0 && a.db_stride_words <= 2048 * 8) {
         if (n_items == 0) return hipSuccess;
         const bool argmin = write_keys || variant == 3;

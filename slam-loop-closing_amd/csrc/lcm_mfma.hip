@@ -121,6 +121,119 @@ hipError_t launch_score_mfma(const MfmaArgs& a, uint32_t n_items, hipStream_t st
     return hipGetLastError();
 }
 
+// ---- the same search on the block-scaled fp4 matrix instruction (variant 5) -------------------------------------------
+// v_mfma_scale_f32_32x32x64_f8f6f4 with fp4 (e2m1) operands: +1 = 0x2, -1 = 0xA, every block scale 1.0 (E8M0 0x7F).
+// 64 bits of a descriptor per instruction at the cycles the int8 form spends on 32, and half the operand bytes:
+// a tile of 32 rows is 4 k-steps x 64 lanes x 16 bytes = 4 KiB.  Products are +-1 and sums stay below 2^24: the f32
+// accumulator holds <q, t> exactly.  One workgroup = 512 query rows (each wave keeps 4 query tiles = 64 VGPRs).
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_expand_fp4(const uint32_t* rows, const int32_t* counts, uint32_t stride_words,
+                                                    uint32_t tiles_per_frame, uint8_t* img) {
+    const uint32_t tile = blockIdx.x, frame = blockIdx.y;
+    const int n = counts[frame];
+    if ((int)(tile * 32) >= n) return;
+    const uint32_t ks = threadIdx.x >> 6, lane = threadIdx.x & 63;             // 4 k-steps of 64 bits
+    const uint32_t r = min(tile * 32 + (lane & 31), (uint32_t)(n - 1));
+    const uint32_t h = lane >> 5;
+    const uint32_t word = rows[(size_t)frame * stride_words + (size_t)r * 8 + ks * 2 + h];   // bits [64 ks + 32 h, +32)
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v |= (((word >> (8 * i + b)) & 1u) ? 0x2u : 0xAu) << (4 * b);
+        o[i] = v;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(img + ((size_t)frame * tiles_per_frame + tile) * FP4_TILE_BYTES) + ks * 64 + lane;
+    *dst = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+hipError_t launch_expand_fp4(const uint32_t* rows, const int32_t* counts, uint32_t stride_words, uint32_t n_frames,
+                             uint32_t tiles_per_frame, uint8_t* img, hipStream_t st) {
+    if (n_frames == 0 || tiles_per_frame == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_expand_fp4, dim3(tiles_per_frame, n_frames), dim3(256), 0, st, rows, counts, stride_words, tiles_per_frame, img);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ float max16f(const v16f& c) {
+    float m = fmaxf(fmaxf(c[0], c[1]), c[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, c[i]), c[i + 1]);
+    return fmaxf(m, c[15]);
+}
+
+__global__ __launch_bounds__(256, 3) void k_score_mfma_fp4(MfmaArgs a) {
+    __shared__ uint4 atile[2][256];                             // two 4 KiB stored-frame tiles
+    const MfmaItem it = a.items[blockIdx.x];
+    if (it.n_slots == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = a.q_counts[it.q_frame];
+    const uint32_t qt0 = it.q_chunk * 16 + (uint32_t)wave * 4;  // this wave's four query tiles (chunk = 512 rows)
+    const uint32_t nq_tiles = (uint32_t)(nq + 31) / 32;
+    constexpr int SCALE_ONE = 0x7F7F7F7F;                       // E8M0 127 = 2^0 in every byte
+
+    v8i b[4][4];
+    {
+        const uint4* qb = reinterpret_cast<const uint4*>(a.q_pm1 + ((size_t)it.q_frame * a.q_tiles_per_frame + qt0) * FP4_TILE_BYTES);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 x = make_uint4(0, 0, 0, 0);
+                if (qt0 + t < nq_tiles) x = qb[t * 256 + ks * 64 + lane];
+                b[t][ks] = v8i{(int)x.x, (int)x.y, (int)x.z, (int)x.w, 0, 0, 0, 0};
+            }
+    }
+
+    for (uint32_t s = 0; s < it.n_slots; ++s) {
+        const uint32_t slot = it.slot_begin + s;
+        const int nt = a.db_counts[slot];
+        const uint32_t nt_tiles = (uint32_t)(nt + 31) / 32;
+        const uint4* tb = reinterpret_cast<const uint4*>(a.db_pm1 + (size_t)slot * a.db_tiles_per_frame * FP4_TILE_BYTES);
+        float best[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+        if (nt_tiles > 0) {
+            uint4 g = tb[tid];
+            atile[0][tid] = g;
+            __syncthreads();
+            for (uint32_t t = 0; t < nt_tiles; ++t) {
+                const int cur = (int)(t & 1);
+                if (t + 1 < nt_tiles) g = tb[(size_t)(t + 1) * 256 + tid];
+                v16f acc[4] = {{0}, {0}, {0}, {0}};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const uint4 x = atile[cur][ks * 64 + lane];
+                    const v8i av = v8i{(int)x.x, (int)x.y, (int)x.z, (int)x.w, 0, 0, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b[q][ks], acc[q], 4, 4, 0, SCALE_ONE, 0, SCALE_ONE);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) best[q] = fmaxf(best[q], max16f(acc[q]));
+                if (t + 1 < nt_tiles) atile[cur ^ 1][tid] = g;
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) best[q] = fmaxf(best[q], __shfl_xor(best[q], 32, 64));
+        if (lane < 32) {
+            uint32_t* out = a.dist + (size_t)(it.out_offset + s - a.pair_base) * MAX_FUSED_QUERY_ROWS;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t r = (qt0 + (uint32_t)q) * 32 + (uint32_t)lane;
+                if (r < (uint32_t)nq) out[r] = nt > 0 ? (uint32_t)(256 - (int)best[q]) >> 1 : 0xFFFFFFFFu;
+            }
+        }
+    }
+}
+
+hipError_t launch_score_mfma_fp4(const MfmaArgs& a, uint32_t n_items, hipStream_t st) {
+    if (n_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_score_mfma_fp4, dim3(n_items), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 // ---- per-pair fold of the best distances ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a) {
     __shared__ uint32_t red_min, red_sum;

@@ -138,13 +138,16 @@ def test_cfg2_full_database_sampled_vs_oracle_and_sharded(matcher, oracle, pkg):
         matcher.dev_free(d_sc); matcher.dev_free(d_su)
         np.testing.assert_array_equal(sc2, full)
 
-        # the opt-in matrix-core variant: same 470,935 records
-        matcher.set_kernel_variant(4)
-        mfma, _ = run(range(1000), False)
-        mfma_ms = matcher.launch_info().kernel_ms
-        matcher.set_kernel_variant(0)
-        np.testing.assert_array_equal(mfma, full)
-        print(f"cfg2 kernels: distance-only {info.kernel_ms:.1f} ms, argmin {argmin_ms:.1f} ms, matrix-core variant {mfma_ms:.1f} ms")
+        # the opt-in matrix-core variants: same 470,935 records
+        mfma_ms = {}
+        for v in (4, 5):
+            matcher.set_kernel_variant(v)
+            mfma, _ = run(range(1000), False)
+            mfma_ms[v] = matcher.launch_info().kernel_ms
+            matcher.set_kernel_variant(0)
+            np.testing.assert_array_equal(mfma, full)
+        print(f"cfg2 kernels: distance-only {info.kernel_ms:.1f} ms, argmin {argmin_ms:.1f} ms, "
+              f"matrix-core int8 {mfma_ms[4]:.1f} ms, fp4 {mfma_ms[5]:.1f} ms")
 
         rng = np.random.default_rng(7)
         qs = rng.integers(gap, 1000, 200)

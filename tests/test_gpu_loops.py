@@ -229,7 +229,7 @@ def test_snapshot_restore_round_trip(matcher, pkg, tmp_path):
         matcher.clear()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_every_kernel_variant_is_bit_exact(matcher, oracle, pkg, variant):
     """0/1: row-per-lane (distances / argmin); 2/3: north_star's train-row-per-lane mapping with LDS-staged queries;
     4: the opt-in matrix-core variant (v_mfma_i32_32x32x32_i8 over +1/-1 operands)."""
@@ -524,16 +524,17 @@ def test_batched_match_lists_equal_match_features_per_pair(matcher, oracle, pkg)
         matcher.clear()
 
 
+@pytest.mark.parametrize("variant", [4, 5])
 @pytest.mark.parametrize("n_frames,max_desc,gap,seed", [(30, 2000, 2, 3), (50, 700, 1, 4), (64, 90, 3, 5), (20, 1300, 2, 6)])
-def test_matrix_core_variant_is_bit_exact(matcher, oracle, pkg, n_frames, max_desc, gap, seed):
-    """lcm_set_kernel_variant(4): self and external query sets, ragged frames (row counts not multiples of 32 / 256),
+def test_matrix_core_variant_is_bit_exact(matcher, oracle, pkg, n_frames, max_desc, gap, seed, variant):
+    """lcm_set_kernel_variant(4 = int8 / 5 = fp4 matrix instruction): self and external query sets, ragged frames (row counts not multiples of 32 / 256),
     an empty and a 1-row frame, exact duplicates (distance 0), and the fused loop test on top of it."""
     fs = pkg.synth.make_frames(n_frames, max_desc, seed=seed, ragged=True, dup_frac=0.4)
     fs.counts[4] = 0
     fs.counts[9] = 1
     fs.rows[7, :20] = fs.rows[3, :20]
     matcher.set_params(min_gap=gap)
-    matcher.set_kernel_variant(4)
+    matcher.set_kernel_variant(variant)
     d_rows = matcher.dev_alloc(fs.rows.nbytes)
     d_counts = matcher.dev_alloc(fs.counts.nbytes)
     try:

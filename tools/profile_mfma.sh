@@ -1,18 +1,18 @@
 #!/bin/bash
-# rocprofv3 evidence for the opt-in matrix-core variant (bench.py --variant 4): kernel statistics, then SQ counters.
+# rocprofv3 evidence for the opt-in matrix-core variant (bench.py --variant ${VAR:-4}): kernel statistics, then SQ counters.
 set -u
 TAG=${1:-r02}
-OUT=$PWD/gpurun_out/${TAG}_mfma
+OUT=$PWD/gpurun_out/${TAG}_mfma${VAR:-4}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 B="python3 $PWD/bench.py"
-rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format csv -- $B --variant 4 --cpu-seconds 0 --no-extras > "$OUT/kt_bench.json" 2> "$OUT/kt.log"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format csv -- $B --variant ${VAR:-4} --cpu-seconds 0 --no-extras > "$OUT/kt_bench.json" 2> "$OUT/kt.log"
 echo "kt rc=$?"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d "$OUT/sq" -o p --output-format csv -- $B --variant 4 --steps 1 --warmup 0 --cpu-seconds 0 --no-extras > /dev/null 2> "$OUT/sq.log"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -d "$OUT/sq" -o p --output-format csv -- $B --variant ${VAR:-4} --steps 1 --warmup 0 --cpu-seconds 0 --no-extras > /dev/null 2> "$OUT/sq.log"
 echo "sq rc=$?"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES SQ_INSTS_MFMA -d "$OUT/sq2" -o p --output-format csv -- $B --variant 4 --steps 1 --warmup 0 --cpu-seconds 0 --no-extras > /dev/null 2> "$OUT/sq2.log"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES SQ_INSTS_MFMA -d "$OUT/sq2" -o p --output-format csv -- $B --variant ${VAR:-4} --steps 1 --warmup 0 --cpu-seconds 0 --no-extras > /dev/null 2> "$OUT/sq2.log"
 echo "sq2 rc=$?"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o p --output-format csv -- $B --variant 4 --steps 1 --warmup 0 --cpu-seconds 0 --no-extras > /dev/null 2> "$OUT/fetch.log"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o p --output-format csv -- $B --variant ${VAR:-4} --steps 1 --warmup 0 --cpu-seconds 0 --no-extras > /dev/null 2> "$OUT/fetch.log"
 echo "fetch rc=$?"
 find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
 cat "$OUT/kt/kt_kernel_stats.csv" | cut -c1-160
