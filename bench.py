@@ -33,6 +33,9 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # 4 cycles per wave64 instruction per SIMD => 48 SIMD-cycles per 64 distances; 256 CUs x 4 SIMDs at 2.4 GHz.
 VALU_PEAK_DIST_PER_S = 256 * 4 * 64 / 48.0 * 2.4e9
 VALU_NOMINAL_DIST_PER_S = 256 * 4 * 64 / 32.0 * 2.4e9      # if every one of the 16 instructions issued in 2 cycles
+# dense matrix-core peaks (MI355X_MICROARCH.md: bf16 ~2.5 PF dense; int8 = 2x bf16 per clock, fp4 = 4x)
+MFMA_I8_PEAK_OPS = 5.0e15
+MFMA_FP4_PEAK_OPS = 10.0e15
 
 WORKLOADS = {
     # name: (frames, descriptors per frame, description)
@@ -463,6 +466,29 @@ def main():
         search((send if multi else scores).data_ptr(), cap if multi else n_local)      # leave the headline's outputs behind
         m.sync()
 
+    # OPT-IN matrix-core variants (north_star rules MFMA out of the product path; these are measurements of what the
+    # rule costs): same workload, same records — compared here — on v_mfma_i32_32x32x32_i8 / the block-scaled fp4 MFMA
+    mfma = None
+    if args.variant in (0, 1) and not fused and not multi and not args.no_extras:
+        mfma = {}
+        ref = scores.clone()
+        for v, name, peak in ((4, "int8", MFMA_I8_PEAK_OPS), (5, "fp4", MFMA_FP4_PEAK_OPS)):
+            m.set_kernel_variant(v)
+            ms = []
+            for _ in range(3):
+                m.all_vs_all(scores.data_ptr(), n_local, **q_args)
+                ms.append(m.launch_info().kernel_ms)
+            torch.cuda.synchronize(dev)
+            t_ms = float(np.mean(ms[1:]))                        # the first call also builds the operand image
+            ops = 2.0 * 256.0 * local_dist / (t_ms * 1e-3)       # one multiply-add per descriptor bit per distance
+            mfma[name] = {"kernel_variant": v, "ms_per_pass": t_ms, "distances_per_s": local_dist / (t_ms * 1e-3),
+                          "records_equal_to_headline": bool(torch.equal(scores, ref)),
+                          "roofline": {"bound": "mfma", "achieved": ops / 1e12, "peak": peak / 1e12, "unit": "TOP/s",
+                                       "frac": ops / peak}}
+        m.set_kernel_variant(0)
+        search(scores.data_ptr(), n_local)
+        m.sync()
+
     tot = torch.tensor([local_dist, int(info.pairs), int(info.algo_bytes)], dtype=torch.int64, device=cdev)
     if multi:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -551,6 +577,19 @@ def main():
                 "kernel_ms": other_ms, "distances_per_s": local_dist / (other_ms * 1e-3)},
             "cpu_baseline": cpu,
         }
+        if args.variant in (4, 5):
+            # an explicit --variant 4 / 5 run: the dominant kernel is MFMA-bound, say so in the contract's roofline
+            peak = MFMA_I8_PEAK_OPS if args.variant == 4 else MFMA_FP4_PEAK_OPS
+            ops = 2.0 * 256.0 * local_dist / (kern_ms * 1e-3)
+            out["roofline_hbm"] = out["roofline"]
+            out["roofline"] = {"bound": "mfma", "achieved": ops / 1e12, "peak": peak / 1e12, "unit": "TOP/s", "frac": ops / peak,
+                               "traffic": None, "kernel": "k_score_mfma" + ("_fp4" if args.variant == 5 else ""), "kernel_ms": kern_ms,
+                               "note": "OPT-IN variant, not the product default (north_star: no MFMA); kernel_ms = score + fold kernels"}
+        if mfma is not None:
+            out["matrix_core_variants"] = {
+                "note": "OPT-IN (lcm_set_kernel_variant 4 / 5), not the product path and not the headline: BASELINE.json's "
+                        "north_star rules MFMA out; this is what that rule costs on this workload, bit-identical records",
+                **mfma}
         if multi:
             out["merged_shards_vs_oracle_sample_mismatches"] = merged_mismatch
         if fused:
