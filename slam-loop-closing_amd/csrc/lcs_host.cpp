@@ -29,7 +29,21 @@ LoopClosingSystem::LoopClosingSystem(double loop_threshold, int min_loop_gap, in
     if (lcm_create(&p, device_id, nullptr, &matcher_) != LCM_OK) raise("LoopClosingSystem: lcm_create");
 }
 
-LoopClosingSystem::~LoopClosingSystem() { lcm_destroy(matcher_); }
+LoopClosingSystem::LoopClosingSystem(double loop_threshold, int min_loop_gap, const std::vector<int>& device_ids)
+    : loop_threshold_(loop_threshold), min_loop_gap_(min_loop_gap), shard_rank_(0), shard_world_(1) {
+    if (device_ids.empty()) throw std::invalid_argument("LoopClosingSystem: empty device list");
+    lcm_params p;
+    lcm_params_default(&p);
+    p.sim_threshold = loop_threshold;
+    p.min_gap = min_loop_gap;
+    if (lcm_group_create(&p, (int)device_ids.size(), device_ids.data(), &group_) != LCM_OK) raise("LoopClosingSystem: lcm_group_create");
+    if (lcm_group_handle(group_, 0, &matcher_) != LCM_OK) { lcm_group_destroy(group_); group_ = nullptr; raise("LoopClosingSystem: lcm_group_handle"); }
+}
+
+LoopClosingSystem::~LoopClosingSystem() {
+    if (group_) lcm_group_destroy(group_);      // owns every shard's matcher, matcher_ included
+    else lcm_destroy(matcher_);
+}
 
 const Frame* LoopClosingSystem::findFrame(int frame_id) const {
     auto it = std::lower_bound(frames_.begin(), frames_.end(), frame_id, [](const Frame& f, int id) { return f.id < id; });
@@ -55,8 +69,10 @@ void LoopClosingSystem::processFrame(const uint8_t* descriptors, int rows, int n
         loop_closures_.insert(loop_closures_.end(), found.begin(), found.end());
         // ... then the frame joins the device database if this rank owns its position
         const size_t pos = frames_.size() - 1;
-        if (ownsPosition(pos)) {
-            const Frame& s = frames_.back();
+        const Frame& s = frames_.back();
+        if (group_) {
+            if (lcm_group_append(group_, s.id, s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_group_append");
+        } else if (ownsPosition(pos)) {
             if (lcm_db_append(matcher_, s.id, s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_db_append");
         }
     } catch (...) {
@@ -82,14 +98,16 @@ std::vector<LoopCandidate> LoopClosingSystem::detectLoops(int current_frame_id) 
     static_assert(sizeof(LoopCandidate) == sizeof(lcm_loop_candidate), "LoopCandidate layout");
     const Frame* cur = findFrame(current_frame_id);
     if (!cur) throw std::out_of_range("detectLoops: unknown frame id");
-    const int cap = std::max(lcm_db_size(matcher_), 1);
+    const int cap = std::max(group_ ? lcm_group_db_size(group_) : lcm_db_size(matcher_), 1);
     std::vector<LoopCandidate> out((size_t)cap);
     int n = 0;
     static const uint8_t dummy[32] = {0};
     const uint8_t* q = cur->rows() > 0 ? cur->descriptors.data() : dummy;
-    if (lcm_detect_loops(matcher_, current_frame_id, q, cur->rows(), cur->num_keypoints,
-                         reinterpret_cast<lcm_loop_candidate*>(out.data()), cap, &n) != LCM_OK)
-        raise("detectLoops");
+    const int rc = group_ ? lcm_group_detect_loops(group_, current_frame_id, q, cur->rows(), cur->num_keypoints,
+                                                   reinterpret_cast<lcm_loop_candidate*>(out.data()), cap, &n)
+                          : lcm_detect_loops(matcher_, current_frame_id, q, cur->rows(), cur->num_keypoints,
+                                             reinterpret_cast<lcm_loop_candidate*>(out.data()), cap, &n);
+    if (rc != LCM_OK) raise("detectLoops");
     out.resize((size_t)n);
     return out;
 }
@@ -102,13 +120,28 @@ std::vector<std::vector<DMatch>> LoopClosingSystem::matchLoopClosures(int curren
         if (c.current_frame_id == current_frame_id) trains.push_back(c.matched_frame_id);
     std::vector<std::vector<DMatch>> lists(trains.size());
     if (trains.empty()) return lists;
-    std::vector<DMatch> flat((size_t)std::max(cur->rows(), 1) * trains.size());
-    std::vector<size_t> offs(trains.size() + 1, 0);
     static const uint8_t dummy[32] = {0};
-    if (lcm_match_query_batch(matcher_, cur->rows() > 0 ? cur->descriptors.data() : dummy, cur->rows(), trains.data(), (int)trains.size(),
-                              reinterpret_cast<lcm_dmatch*>(flat.data()), flat.size(), offs.data(), nullptr) != LCM_OK)
-        raise("matchLoopClosures");
-    for (size_t i = 0; i < trains.size(); ++i) lists[i].assign(flat.begin() + (ptrdiff_t)offs[i], flat.begin() + (ptrdiff_t)offs[i + 1]);
+    const uint8_t* q = cur->rows() > 0 ? cur->descriptors.data() : dummy;
+    // one launch per device that stores some of the matched frames (one launch in all without a group)
+    const int world = group_ ? lcm_group_size(group_) : 1;
+    for (int r = 0; r < world; ++r) {
+        std::vector<int32_t> mine;
+        std::vector<size_t> where;
+        for (size_t i = 0; i < trains.size(); ++i) {
+            const Frame* t = findFrame(trains[i]);
+            const size_t pos = t ? (size_t)(t - frames_.data()) : 0;
+            if (!group_ || (int)(pos % (size_t)world) == r) { mine.push_back(trains[i]); where.push_back(i); }
+        }
+        if (mine.empty()) continue;
+        lcm_handle* h = matcher_;
+        if (group_ && lcm_group_handle(group_, r, &h) != LCM_OK) raise("matchLoopClosures: lcm_group_handle");
+        std::vector<DMatch> flat((size_t)std::max(cur->rows(), 1) * mine.size());
+        std::vector<size_t> offs(mine.size() + 1, 0);
+        if (lcm_match_query_batch(h, q, cur->rows(), mine.data(), (int)mine.size(), reinterpret_cast<lcm_dmatch*>(flat.data()), flat.size(),
+                                  offs.data(), nullptr) != LCM_OK)
+            raise("matchLoopClosures");
+        for (size_t k = 0; k < mine.size(); ++k) lists[where[k]].assign(flat.begin() + (ptrdiff_t)offs[k], flat.begin() + (ptrdiff_t)offs[k + 1]);
+    }
     return lists;
 }
 

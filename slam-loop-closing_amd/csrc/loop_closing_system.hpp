@@ -19,6 +19,7 @@
 #include <vector>
 
 struct lcm_handle;
+struct lcm_group;
 
 namespace loop_closing {
 
@@ -51,6 +52,10 @@ public:
     // reference's two-argument construction valid.
     explicit LoopClosingSystem(double loop_threshold = 0.7, int min_loop_gap = 30, int device_id = 0,
                                int shard_rank = 0, int shard_world = 1);
+    // The same system over SEVERAL MI355X of one node (one process): stored frames are sharded cyclically over
+    // `device_ids` behind an lcm_group (one matcher + host thread per device, RCCL inside); every member function
+    // behaves as with one device and returns the same results.  A C++ host needs no RCCL code of its own.
+    LoopClosingSystem(double loop_threshold, int min_loop_gap, const std::vector<int>& device_ids);
     ~LoopClosingSystem();
     LoopClosingSystem(const LoopClosingSystem&) = delete;
     LoopClosingSystem& operator=(const LoopClosingSystem&) = delete;
@@ -92,6 +97,7 @@ private:
     std::vector<LoopCandidate> loop_closures_;
     std::vector<DMatch> consecutive_matches_;
     lcm_handle* matcher_ = nullptr;      // stands where cv::Ptr<cv::BFMatcher> matcher_ stood (hpp:73)
+    lcm_group* group_ = nullptr;  // multi-device construction: the shards' matchers live in here (matcher_ = shard 0's)
     double loop_threshold_;              // hpp:75
     int min_loop_gap_;                   // hpp:76
     int shard_rank_, shard_world_;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
+#include <memory>
 #include <vector>
 
 #include "../../slam-loop-closing_amd/csrc/loop_closing_system.hpp"
@@ -21,8 +22,13 @@ int main(int argc, char** argv) {
     const int n_frames = argc > 1 ? atoi(argv[1]) : 24;
     const int rows = argc > 2 ? atoi(argv[2]) : 300;
     const char* out_dir = argc > 3 ? argv[3] : "/tmp/lcm_demo_results";
+    const bool group_mode = argc > 4 && argv[4][0] == 'g';  // "group": the multi-device constructor over device 0
     try {
-        loop_closing::LoopClosing system(0.15, 5);            // north_star's spelling; README.md:108-109 style values
+        // north_star's spelling of the class; README.md:108-109 style values.  In group mode the SAME program runs on
+        // an lcm_group (RCCL communicator, cyclic sharding) with no collective code of its own.
+        std::unique_ptr<loop_closing::LoopClosing> holder(group_mode ? new loop_closing::LoopClosing(0.15, 5, std::vector<int>{0})
+                                                                     : new loop_closing::LoopClosing(0.15, 5));
+        loop_closing::LoopClosing& system = *holder;
         const int n_places = 4;
         std::vector<std::vector<uint8_t>> place(n_places, std::vector<uint8_t>((size_t)rows * 32));
         for (auto& p : place) for (auto& b : p) b = (uint8_t)next_u64();
@@ -44,6 +50,20 @@ int main(int argc, char** argv) {
             const auto m = system.matchFeatures(*system.findFrame(c.current_frame_id), *system.findFrame(c.matched_frame_id));
             printf("MATCHES %d %d %zu\n", c.current_frame_id, c.matched_frame_id, m.size());
             for (const auto& x : m) printf("M %d %d %d %g\n", x.queryIdx, x.trainIdx, x.imgIdx, x.distance);
+        }
+        {   // README.md:101: re-match features on identified loop frames — all of the busiest frame's closures, one launch
+            int busiest = -1; size_t most = 0;
+            for (const auto& c : system.getLoopClosures()) {
+                size_t n = 0;
+                for (const auto& d : system.getLoopClosures()) n += d.current_frame_id == c.current_frame_id;
+                if (n > most) { most = n; busiest = c.current_frame_id; }
+            }
+            if (busiest >= 0) {
+                const auto lists = system.matchLoopClosures(busiest);
+                printf("RELISTS %d %zu", busiest, lists.size());
+                for (const auto& l : lists) printf(" %zu", l.size());
+                printf("\n");
+            }
         }
         system.saveResults(out_dir);
         try {

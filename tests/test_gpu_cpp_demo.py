@@ -50,5 +50,15 @@ def test_cpp_demo_matches_oracle(tmp_path, pkg, oracle):
     for l, w in zip(ms, om):
         assert (int(l[1]), int(l[2]), int(l[3]), float(l[4])) == (int(w["query_idx"]), int(w["train_idx"]), 0, float(w["distance"]))
     assert any(l.startswith("EXPECTED_EXCEPTION") for l in lines)
+    # matchLoopClosures: list sizes == num_matches of the busiest frame's closures
+    rel = [l.split() for l in lines if l.startswith("RELISTS ")][0]
+    busiest = int(rel[1])
+    mine = want[want["current_frame_id"] == busiest]
+    assert int(rel[2]) == len(mine) and [int(x) for x in rel[3:]] == [int(x) for x in mine["num_matches"]]
+    # the multi-device constructor (an lcm_group over device 0: RCCL communicator, cyclic sharding) prints the same
+    res2 = subprocess.run([exe, str(n_frames), str(rows), out_dir + "_g", "group"], capture_output=True, text=True, timeout=300)
+    assert res2.returncode == 0, res2.stderr
+    keep = lambda txt: [l for l in txt.strip().split("\n") if l.split(" ")[0] in ("FRAMES", "LOOP", "MATCHES", "M", "RELISTS")]
+    assert keep(res2.stdout) == keep(res.stdout)
     txt = open(os.path.join(out_dir, "loop_closures.txt")).read()
     assert f"Loop closures detected: {len(want)}" in txt
