@@ -44,6 +44,7 @@ def test_cfg4_fullsize_fused_filter_and_loop_test(pkg, oracle):
         # so 2 x min keeps all 2000 matches): the candidate buffer must hold one record per pair
         cands, n_pairs = m.all_vs_all_loops(out=np.zeros(12352935, pkg.capi.CANDIDATE_DTYPE))
         info = m.launch_info()
+        print(f"cfg4 fused: score kernel {info.kernel_ms:.0f} ms = {info.distances / info.kernel_ms / 1e9:.3f}e12 distances/s, loop-test kernels {info.aux_kernel_ms:.3f} ms")
         assert n_pairs == 12352935 == pkg.synth.n_pairs_all_vs_all(5000, GAP)
         assert info.distances == n_pairs * 2000 * 2000 and info.aux_kernel_ms > 0
         scores = m.last_bulk_scores()
@@ -111,6 +112,7 @@ def test_cfg3_rank_slice_of_the_sharded_search(pkg, oracle):
         m.sync()
         m.dev_download(d_scores, local)
         info = m.launch_info()
+        print(f"cfg3 rank slice: kernel {info.kernel_ms:.0f} ms = {info.distances / info.kernel_ms / 1e9:.3f}e12 distances/s")
         for x in (d_scores, d_rows, d_counts):
             m.dev_free(x)
 
@@ -169,6 +171,7 @@ def test_cfg5_rank_slice_streaming(pkg, oracle):
             take(t)
         assert len(m) == 2500
         st = m.online_stats()
+        print(f"cfg5 rank slice (online, batches of 8): kernels {st.kernel_ms:.0f} ms = {st.distances / st.kernel_ms / 1e9:.3f}e12 distances/s in {st.launches} launches")
         assert st.queries == n_frames and st.pairs == 24922560 and st.distances == 24922560 * 2000 * 2000 and st.kernel_ms > 0
     er = pkg.sharding.shard_eligible_counts(fs.ids, GAP, rank, world)
     assert [len(x) for x in out] == er.tolist()
