@@ -536,7 +536,8 @@ def main():
         if os.path.exists(tp):
             try:
                 t = json.load(open(tp))
-                if t.get("workload") == wl and t.get("n_gpus") == world and t.get("frames") == n_frames:
+                if (t.get("workload") == wl and t.get("n_gpus") == world and t.get("frames") == n_frames
+                        and t.get("kernel_variant", 0) == args.variant and not fused):
                     traffic = t.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

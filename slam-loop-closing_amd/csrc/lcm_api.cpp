@@ -583,7 +583,11 @@ static int pair_keys(lcm_handle* h, RowSrc q, RowSrc t, std::vector<uint32_t>& k
             for (int r = t.n; r < padded_rows(t.n) + ROW_PAD; ++r) memcpy(dst + (size_t)r * LCM_DESC_BYTES, t.host + (size_t)(t.n - 1) * LCM_DESC_BYTES, LCM_DESC_BYTES);
         }
     }
-    if (q.dev || t.dev) { rc = wait_db(h); if (rc) return rc; }
+    if (q.dev || t.dev) {
+        rc = wait_db(h); if (rc) return rc;
+        if ((size_t)h->cap_frames * (size_t)h->stride_rows >= 0xFFFFFFFFull)
+            return fail(LCM_ERR_CAPACITY, "the database arena exceeds 2^32 rows: pair items address rows with 32 bits");
+    }
     // device-resident sides are addressed from the arena base (row index = byte offset / 32)
     std::vector<PairJob> jobs(1);
     jobs[0].nq = q.n; jobs[0].nt = t.n;
@@ -724,6 +728,8 @@ static int match_batch_impl(lcm_handle* h, const uint8_t* q_host, int nq_host, c
                         (uint32_t)((size_t)(t.dev - h->d_rows) / LCM_DESC_BYTES), t.n});
     }
     rc = wait_db(h); if (rc) return rc;
+    if ((size_t)h->cap_frames * (size_t)h->stride_rows >= 0xFFFFFFFFull)
+        return fail(LCM_ERR_CAPACITY, "the database arena exceeds 2^32 rows: pair items address rows with 32 bits");
     const uint32_t* keys = nullptr;
     std::vector<size_t> row0;
     rc = run_pair_jobs(h, h->d_rows, h->d_rows, q_host != nullptr, false, stage_bytes, jobs, &keys, row0); if (rc) return rc;
@@ -790,6 +796,8 @@ static void account_prefix(lcm_handle* h, int nq, int n_elig) {
 static int cross_score_prefixes(lcm_handle* h, const uint8_t* d_qbase, const uint32_t* q_row0, const int* nq, const int* elig,
                                 int n_q, lcm_score* d_scores, uint32_t* d_idx_sums) {
     const int CH = lcm::MAX_FUSED_QUERY_ROWS;
+    if ((size_t)h->cap_frames * (size_t)h->stride_rows >= 0xFFFFFFFFull)
+        return fail(LCM_ERR_CAPACITY, "the database arena exceeds 2^32 rows: pair items address rows with 32 bits");
     constexpr size_t SLOT_BUDGET = 49152;                 // key slots of 8 KB per chunk: 384 MB of scratch
     std::vector<lcm::PairItem> fitems, bitems;
     std::vector<lcm::CrossDesc> descs;

@@ -90,3 +90,62 @@ def test_bulk_and_online_paths_equal_oracle(matcher, oracle, db):
     finally:
         matcher.set_params(min_gap=30, min_matches=50, sim_threshold=0.15)
         matcher.clear()
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(small_databases(), st.sampled_from([0, 1, 2]), st.sampled_from([0, 1, 4, 5]))
+def test_every_bulk_route_equals_oracle(matcher, oracle, db, cross, variant):
+    """The round-2 routes through the same random ragged databases: lcm_all_vs_all_argmin (records + index checksum),
+    cross_check 0 / 1 / 2, kernel variants 0 / 1 / 4 / 5, micro-batched online queries, batched match lists."""
+    rows, counts, ids, gap = db
+    matcher.set_params(min_gap=gap, min_matches=1, sim_threshold=0.0, cross_check=cross)
+    matcher.set_kernel_variant(variant)
+    p = oracle.default_params(min_gap=gap, min_matches=1, sim_threshold=0.0, cross_check=cross)
+    n_frames = len(counts)
+    try:
+        matcher.clear()
+        for f in range(n_frames):
+            matcher.append(int(ids[f]), rows[f, : counts[f]])
+        pq, pt = [], []
+        for c in range(n_frames):
+            for t in range(n_frames):
+                if ids[c] - ids[t] >= max(gap, 1):
+                    pq.append(c); pt.append(t)
+        want, wsums = oracle.fast_score_pairs_idx(rows, counts, pq, pt, p, n_threads=2)
+        n, offs = matcher.all_vs_all_plan()
+        assert n == len(pq)
+        if n:
+            d, ds = matcher.dev_alloc(n * 8), matcher.dev_alloc(n * 4)
+            got, sums = np.zeros(n, want.dtype), np.zeros(n, np.uint32)
+            matcher.all_vs_all(d, n)
+            matcher.sync(); matcher.dev_download(d, got)
+            np.testing.assert_array_equal(got, want)
+            matcher.all_vs_all_argmin(d, n, ds)
+            matcher.sync(); matcher.dev_download(d, got); matcher.dev_download(ds, sums)
+            matcher.dev_free(d); matcher.dev_free(ds)
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(sums, wsums)
+        # the last three frames as one micro-batch against the frames before them
+        k = min(3, n_frames)
+        first = n_frames - k
+        if ids[n_frames - 1] - ids[first] < max(gap, 1) or k == 1:       # exactness condition of a batch
+            matcher.clear()
+            for f in range(first):
+                matcher.append(int(ids[f]), rows[f, : counts[f]])
+            t = matcher.query_submit_batch([rows[f, : counts[f]] for f in range(first, n_frames)], [int(ids[f]) for f in range(first, n_frames)])
+            sc, boffs = matcher.query_collect_batch(t)
+            for j, f in enumerate(range(first, n_frames)):
+                np.testing.assert_array_equal(sc[int(boffs[j]): int(boffs[j + 1])], want[int(offs[f]): int(offs[f + 1])])
+            for f in range(first, n_frames):
+                matcher.append(int(ids[f]), rows[f, : counts[f]])
+        # match lists of a few pairs in one launch
+        pairs = list(zip(pq, pt))[:5]
+        if pairs:
+            lists, mins = matcher.match_stored_batch([(int(ids[a]), int(ids[b])) for a, b in pairs])
+            for (a, b), got_l in zip(pairs, lists):
+                om, _ = oracle.match_features(rows[a, : counts[a]], rows[b, : counts[b]], p)
+                np.testing.assert_array_equal(got_l, om.astype(got_l.dtype))
+    finally:
+        matcher.set_kernel_variant(0)
+        matcher.set_params(min_gap=30, min_matches=50, sim_threshold=0.15, cross_check=0)
+        matcher.clear()

@@ -25,6 +25,7 @@ launches = max(nf, 1)
 out = {
     "workload": sys.argv[6] if len(sys.argv) > 6 else "cfg2", "frames": int(sys.argv[4]) if len(sys.argv) > 4 else 1000,
     "n_gpus": int(sys.argv[5]) if len(sys.argv) > 5 else 1, "kernel": KERNEL, "launches_profiled": launches,
+    "kernel_variant": 1 if "8, 1, false" in KERNEL else 0,      # bench.py reports the figure only for the matching --variant
     "FETCH_SIZE_KB_per_launch": fetch_kb / launches, "WRITE_SIZE_KB_per_launch": write_kb / max(nw, 1),
     # FETCH_SIZE = TCC_EA0_RDREQ x 64 B / 1024.  This kernel's reads are 64-byte scalar loads (s_load_dwordx16) plus a
     # few 16-byte vector loads, not the 16 B/lane wide streaming pattern for which the guide measured the counter at
