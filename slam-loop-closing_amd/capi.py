@@ -13,7 +13,8 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblcm_hip.so")
+# LCM_LIB_PATH: test plumbing only (e.g. the host-sanitizer build of the same sources, `make -C csrc asan`)
+LIB_PATH = os.environ.get("LCM_LIB_PATH") or os.path.join(_HERE, "lib", "liblcm_hip.so")
 DESC_BYTES = 32
 KEY_SHIFT = 22
 TUNE_ITEM_SLOTS, TUNE_ONLINE_SPLIT = 0, 1      # lcm_tuning

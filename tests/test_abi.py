@@ -142,3 +142,17 @@ def test_null_handle_calls_fail_cleanly(pkg):
     lib.lcm_destroy(None)                                   # no-op
     assert b"" != lib.lcm_last_error()
     assert lib.lcm_create(C.byref(p), 0, None, None) == -1  # out == NULL
+
+
+def test_headers_are_plain_c99(tmp_path):
+    """The boundary is a C ABI: include/lcm.h and include/lcm_host.h must compile as C99 (no C++-isms), pedantically."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "c_check.c"
+    src.write_text('#include "lcm.h"\n#include "lcm_host.h"\n'
+                   'int main(void) { lcm_params p; lcm_params_default(&p); return (int)(sizeof(lcm_group_info) * 0); }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
