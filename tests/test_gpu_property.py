@@ -92,7 +92,7 @@ def test_bulk_and_online_paths_equal_oracle(matcher, oracle, db):
         matcher.clear()
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(small_databases(), st.sampled_from([0, 1, 2]), st.sampled_from([0, 1, 4, 5]))
 def test_every_bulk_route_equals_oracle(matcher, oracle, db, cross, variant):
     """The round-2 routes through the same random ragged databases: lcm_all_vs_all_argmin (records + index checksum),
