@@ -289,6 +289,11 @@ LCM_API int  lcm_group_last_info(const lcm_group* g, lcm_group_info* info);
  * on the host: a few KB per query). */
 LCM_API int  lcm_group_query_scores(lcm_group* g, const uint8_t* query, int nq, int query_frame_id,
                                     lcm_score* out_scores, int32_t* out_frame_ids, int cap, int* n_out);
+/* lcm_query_submit_batch + lcm_query_collect_batch over all shards: up to 16 frames per launch per device (the
+ * streaming mode of BASELINE.json configs[4] inside one process); records of query 0 first, offsets[n_queries + 1]. */
+LCM_API int  lcm_group_query_scores_batch(lcm_group* g, const uint8_t* const* queries, const int* nq,
+                                          const int* query_frame_ids, int n_queries,
+                                          lcm_score* out_scores, size_t cap, size_t* n_out, size_t* offsets);
 LCM_API int  lcm_group_detect_loops(lcm_group* g, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
                                     lcm_loop_candidate* out, int cap, int* n_out);
 /* Host-only (no device needed): merge W per-shard score arrays — shard r in (query ascending, owned stored ascending)

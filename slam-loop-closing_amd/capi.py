@@ -131,6 +131,7 @@ _SIGNATURES = {
     "lcm_group_all_vs_all": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "lcm_group_last_info": (C.c_int, [_vp, C.POINTER(GroupInfo)]),
     "lcm_group_query_scores": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _i32p]),
+    "lcm_group_query_scores_batch": (C.c_int, [_vp, _vp, _i32p, _i32p, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "lcm_group_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
     "lcm_merge_shard_scores": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_size_t,
                                           C.POINTER(C.c_size_t), _vp]),
@@ -591,6 +592,20 @@ class Group:
         _check(self._lib.lcm_group_query_scores(self._g, _ptr(q), q.shape[0], query_frame_id, scores.ctypes.data_as(_vp),
                                                 ids.ctypes.data_as(_vp), cap, C.byref(n)))
         return scores[: n.value], ids[: n.value]
+
+    def query_scores_batch(self, queries: Sequence[np.ndarray], query_frame_ids: Sequence[int]) -> Tuple[np.ndarray, np.ndarray]:
+        qs = [_rows(q) for q in queries]
+        B = len(qs)
+        ptrs = (_vp * B)(*[q.ctypes.data if q.shape[0] else None for q in qs])
+        nq = np.array([q.shape[0] for q in qs], np.int32)
+        ids = np.ascontiguousarray(query_frame_ids, np.int32)
+        cap = max(len(self), 1) * B
+        scores = np.zeros(cap, SCORE_DTYPE)
+        offs = np.zeros(B + 1, np.uintp)
+        n = C.c_size_t(0)
+        _check(self._lib.lcm_group_query_scores_batch(self._g, ptrs, nq.ctypes.data_as(_i32p), ids.ctypes.data_as(_i32p), B,
+                                                      scores.ctypes.data_as(_vp), cap, C.byref(n), offs.ctypes.data_as(_vp)))
+        return scores[: n.value], offs
 
     def detect_loops(self, current_frame_id: int, query, n_keypoints: int = -1) -> np.ndarray:
         q = _rows(query)

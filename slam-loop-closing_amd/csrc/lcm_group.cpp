@@ -463,6 +463,52 @@ int lcm_group_query_scores(lcm_group* g, const uint8_t* query, int nq, int query
     });
 }
 
+/* Micro-batched online queries over all shards (cfg5 shape in one process): the batch goes to every device with ONE
+ * lcm_query_submit_batch each (all enqueued before any is awaited), the per-shard records are interleaved on the host
+ * into the single-device order, query 0's records first.  offsets: n_queries + 1 entries (optional). */
+int lcm_group_query_scores_batch(lcm_group* g, const uint8_t* const* queries, const int* nq, const int* query_frame_ids, int n_queries,
+                                 lcm_score* out_scores, size_t cap, size_t* n_out, size_t* offsets) {
+    if (!g || !n_out || !queries || !nq || !query_frame_ids || n_queries < 1) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    *n_out = 0;
+    return guarded([&]() -> int {
+        const int W = g->world;
+        std::vector<size_t> offs((size_t)n_queries + 1, 0);
+        std::vector<int> e((size_t)n_queries);
+        for (int b = 0; b < n_queries; ++b) {
+            e[(size_t)b] = eligible_count(g->frames, query_frame_ids[b], g->params.min_gap);
+            offs[(size_t)b + 1] = offs[(size_t)b] + (size_t)e[(size_t)b];
+        }
+        const size_t total = offs.back();
+        if (offsets) memcpy(offsets, offs.data(), sizeof(size_t) * offs.size());
+        if (total > cap) return fail(LCM_ERR_CAPACITY, "%zu score records but room for %zu", total, cap);
+        if (total > 0 && !out_scores) return fail(LCM_ERR_INVALID_ARG, "out_scores is NULL");
+        std::vector<int> tickets((size_t)W, -1);
+        int rc_all = LCM_OK;
+        std::string why;
+        for (int r = 0; r < W && !rc_all; ++r) {
+            rc_all = lcm_query_submit_batch(g->h[(size_t)r], queries, nq, query_frame_ids, n_queries, &tickets[(size_t)r]);
+            if (rc_all) why = lcm::last_error();
+        }
+        std::vector<lcm_score> part(std::max<size_t>((total + (size_t)W - 1) / (size_t)W + (size_t)n_queries, 1));
+        std::vector<size_t> poffs((size_t)n_queries + 1);
+        for (int r = 0; r < W; ++r) {
+            if (tickets[(size_t)r] < 0) continue;
+            size_t n = 0;
+            const int rc = lcm_query_collect_batch(g->h[(size_t)r], tickets[(size_t)r], part.data(), part.size(), &n, poffs.data());
+            if (rc) { if (!rc_all) { rc_all = rc; why = lcm::last_error(); } continue; }
+            if (rc_all) continue;                         // a submit failed: this collect only drained the ticket
+            for (int b = 0; b < n_queries; ++b) {
+                const int want = e[(size_t)b] > r ? (e[(size_t)b] - r + W - 1) / W : 0;
+                if ((int)(poffs[(size_t)b + 1] - poffs[(size_t)b]) != want) { rc_all = fail(LCM_ERR_HIP, "shard %d returned a wrong record count for query %d", r, b); why = lcm::last_error(); break; }
+                for (int k = 0; k < want; ++k) out_scores[offs[(size_t)b] + (size_t)r + (size_t)k * (size_t)W] = part[poffs[(size_t)b] + (size_t)k];
+            }
+        }
+        if (rc_all) { lcm::last_error() = why; return rc_all; }
+        *n_out = total;
+        return LCM_OK;
+    });
+}
+
 int lcm_group_detect_loops(lcm_group* g, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
                            lcm_loop_candidate* out, int cap, int* n_out) {
     if (!g || !n_out || cap < 0) return fail(LCM_ERR_INVALID_ARG, "bad argument");

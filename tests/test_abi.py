@@ -135,6 +135,7 @@ def test_null_handle_calls_fail_cleanly(pkg):
     assert lib.lcm_group_all_vs_all(None, None, 0, C.byref(z), None) == -1
     assert lib.lcm_group_last_info(None, C.byref(pkg.capi.GroupInfo())) == -1
     assert lib.lcm_group_query_scores(None, buf, 1, 0, buf, buf, 1, C.byref(n)) == -1
+    assert lib.lcm_group_query_scores_batch(None, None, None, None, 1, None, 0, C.byref(z), None) == -1
     assert lib.lcm_group_detect_loops(None, 0, buf, 1, 1, buf, 1, C.byref(n)) == -1
     assert lib.lcm_merge_shard_scores(None, None, 1, None, 0, 0, None, 0, C.byref(z), None) == -1
     assert lib.lcm_merge_shard_scores_device(None, None, None, 1, None, 0, 0, None, 0, C.byref(z)) == -1

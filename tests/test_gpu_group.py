@@ -50,6 +50,15 @@ def test_group_of_one_equals_single_handle(pkg, oracle):
         s2, ids2 = m.query_scores(q, 5000)
         np.testing.assert_array_equal(scores[:60], s2)
         assert ids.tolist()[:60] == ids2.tolist() and len(ids) == 63
+        # micro-batched online queries through the group == the single handle's batch == one by one
+        qb = [extra.frame(k) for k in range(3)]
+        bs, boffs = g.query_scores_batch(qb, [5000, 5001, 5002])
+        t = m.query_submit_batch(qb, [5000, 5001, 5002])
+        ms, moffs_b = m.query_collect_batch(t)
+        assert boffs.tolist() == [0, 63, 126, 189]
+        for k in range(3):
+            np.testing.assert_array_equal(bs[int(boffs[k]): int(boffs[k + 1])][:60], ms[int(moffs_b[k]): int(moffs_b[k + 1])])
+        np.testing.assert_array_equal(bs[63:126], scores)
         c1 = g.detect_loops(5000, q)
         want_c = [i for i in range(63) if m.loop_test(scores[i], len(q), int(fs.counts[i]) if i < 60 else 700)[0]]
         assert c1["matched_frame_id"].tolist() == [int(ids[i]) for i in want_c]
