@@ -128,6 +128,7 @@ def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi,
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     m = pkg.Matcher(p, device=local_rank, stream=stream.cuda_stream)
+    m.set_kernel_variant(args.variant if args.variant in (4, 5) else 0)     # 4 / 5: opt-in matrix-core variants online
     n_frames = fs.n_frames
     assert B == 1 or int(fs.ids[min(B, n_frames) - 1] - fs.ids[0]) < max(args.gap, 1), "a batch must span fewer ids than min_gap"
     owned_n = len(pkg.sharding.owned_positions(n_frames, rank, world))
@@ -200,7 +201,8 @@ def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi,
             "config": {"workload": "STREAMING (online append + micro-batched queries, host rows over PCIe): " + wl_desc,
                        "frames": n_frames, "descriptors_per_frame": fs.stride_rows, "min_gap": args.gap,
                        "pairs_per_step": total_pairs, "distances_per_step": total_dist, "seed": seed,
-                       "stream_batch": B, "sharding": "cyclic by frame" if world > 1 else "none"},
+                       "stream_batch": B, "sharding": "cyclic by frame" if world > 1 else "none",
+                       "kernel_variant": args.variant if args.variant in (4, 5) else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "k_score_rowlane (online launches: score + k_finalize_pairs in split mode)",

@@ -71,6 +71,8 @@ struct QuerySlot {                // everything one in-flight online query owns
     uint8_t* d_query = nullptr;   size_t d_query_bytes = 0;
     lcm_score* d_scores = nullptr; size_t d_scores_n = 0;
     uint32_t* d_dist = nullptr;   size_t d_dist_n = 0;         // split mode: best distance per (pair, row)
+    uint8_t* h_meta = nullptr;    size_t h_meta_bytes = 0;     // matrix-core variants: pinned [row counts | work items]
+    uint8_t* d_meta = nullptr;    size_t d_meta_bytes = 0;
     hipEvent_t done = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;      // around this query's kernel(s): summed into the handle's online stats
     uint64_t acc_pairs = 0, acc_distances = 0, acc_bytes = 0;
@@ -127,7 +129,7 @@ struct lcm_handle {
     uint32_t* h_final_keys = nullptr; size_t h_final_keys_n = 0;      // pair mode: pinned landing zone of the folded keys
     uint8_t* d_xq = nullptr; size_t d_xq_bytes = 0;                   // cross_check: padded copy of an external query set
     // opt-in MFMA variant (4): +1 / -1 int8 operand images of the database and of an external query set, scratch
-    uint8_t* d_pm1 = nullptr; size_t d_pm1_bytes = 0; uint64_t pm1_stamp = 0;
+    uint8_t* d_pm1 = nullptr; size_t d_pm1_bytes = 0; uint64_t pm1_stamp = 0; size_t pm1_frames = 0;   // frames expanded so far
     uint8_t* d_qpm1 = nullptr; size_t d_qpm1_bytes = 0;
     uint32_t* d_mdist = nullptr; size_t d_mdist_n = 0;
     uint8_t* d_mitems = nullptr; size_t d_mitems_bytes = 0;

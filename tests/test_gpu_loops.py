@@ -560,9 +560,26 @@ def test_matrix_core_variant_is_bit_exact(matcher, oracle, pkg, n_frames, max_de
                 if oracle.loop_test(int(got3[k]["good_count"]), cnt3[c], cnt3[t], p)[0]:
                     keep.append((ids3[c], ids3[t], int(got3[k]["good_count"])))
         assert [(int(r["current_frame_id"]), int(r["matched_frame_id"]), int(r["num_matches"])) for r in cands] == keep
-        # online queries and the pair mode keep working (vector-ALU kernels) under variant 4
+        # online queries run on the matrix cores too (single query, stored-frame query, micro-batch); pair mode keeps
+        # the vector-ALU kernels
         sc, _ = matcher.query_scores(fs.frame(n_frames - 1), int(fs.ids[-1]) + 50)
         assert len(sc) == n_frames + 1
+        fs2_rows = np.concatenate([fs.rows, fs.rows[1:2]]); fs2_counts = np.concatenate([fs.counts, fs.counts[1:2]])
+        wq, _, _ = oracle.fast_score_pairs(fs2_rows, fs2_counts, [n_frames - 1] * (n_frames + 1), list(range(n_frames + 1)), p, n_threads=8)
+        np.testing.assert_array_equal(sc, wq)
+        cur = n_frames // 2
+        c_stored = matcher.detect_loops(int(fs.ids[cur]))
+        c_host = matcher.detect_loops(int(fs.ids[cur]), fs.frame(cur))
+        np.testing.assert_array_equal(c_stored, c_host)
+        want_c = oracle.detect_loops(fs.rows, fs.counts, fs.ids, cur, p)
+        np.testing.assert_array_equal(c_stored["matched_frame_id"], want_c["matched_frame_id"])
+        np.testing.assert_array_equal(c_stored["num_matches"], want_c["num_matches"])
+        qb = [fs.frame(4), fs.frame(9), fs.frame(7), fs.frame(n_frames - 1)]          # empty, 1 row, duplicates, full
+        t = matcher.query_submit_batch(qb, [int(fs.ids[-1]) + 60 + k for k in range(4)])
+        bs, boffs = matcher.query_collect_batch(t)
+        for k, f in enumerate((4, 9, 7, n_frames - 1)):
+            wk, _, _ = oracle.fast_score_pairs(fs2_rows, fs2_counts, [f] * (n_frames + 1), list(range(n_frames + 1)), p, n_threads=8)
+            np.testing.assert_array_equal(bs[int(boffs[k]): int(boffs[k + 1])], wk)
         idx, d = matcher.match_pair(fs.frame(2), fs.frame(3))
         oi, od = oracle.bf_match(fs.frame(2), fs.frame(3))
         np.testing.assert_array_equal(idx, oi)
