@@ -248,10 +248,11 @@ LCM_API int  lcm_last_bulk_scores(const lcm_handle* h, const void** d_scores, si
  * 16-row group keys and a re-scan of the winning group); 2 / 3 = the train-row-per-lane mapping with LDS-staged
  * queries and wavefront shuffle reductions, distances only / (dist, idx) keys.
  * 4 = OPT-IN, NOT the product path: BASELINE.json's north_star rules the matrix cores out ("no MFMA"); this variant
- * runs the bulk search (lcm_all_vs_all, lcm_all_vs_all_loops) on v_mfma_i32_32x32x32_i8 over a +1 / -1 int8 image of
+ * runs the search on v_mfma_i32_32x32x32_i8 over a +1 / -1 int8 image of
  * the descriptors (<q,t> = 256 - 2 d, exact) to MEASURE what that rule costs; same records bit for bit.  5 = the same
  * on the block-scaled fp4 instruction (v_mfma_scale_f32_32x32x64_f8f6f4, +1/-1 as e2m1, all scales 1.0, exact in the
- * f32 accumulator).  Online queries, pair mode and lcm_all_vs_all_argmin keep running the vector-ALU kernels. */
+ * f32 accumulator).  4 / 5 serve the bulk search and the online queries (single, stored-frame, micro-batched); pair
+ * mode, cross_check and lcm_all_vs_all_argmin keep running the vector-ALU kernels under them. */
 LCM_API int  lcm_set_kernel_variant(lcm_handle* h, int variant);
 
 /* ---- multi-GPU: one process, W devices, stored frames sharded cyclically by arrival position ------------------- */
