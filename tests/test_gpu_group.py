@@ -123,3 +123,34 @@ def test_device_merge_of_w_shards_equals_host_merge_and_single_device(matcher, p
         matcher.dev_free(d_rows); matcher.dev_free(d_counts)
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+@pytest.mark.parametrize("mode", ["cross1", "cross2", "variant4", "variant5"])
+def test_group_honours_cross_check_and_kernel_variants(pkg, oracle, mode):
+    """The group's search reads its queries from the rank-major gathered buffer (an EXTERNAL query set with an index
+    map): cross_check then works on a padded copy of it, the matrix-core variants on an expanded image of it."""
+    fs = pkg.synth.make_frames(26, 600, seed=33, ragged=True, dup_frac=0.4)
+    fs.counts[5] = 0
+    fs.rows[7, :100] = fs.rows[3, :100]
+    p = pkg.default_params()
+    p.min_gap = 3
+    op = oracle.default_params(min_gap=3)
+    if mode.startswith("cross"):
+        p.cross_check = int(mode[-1])
+        op.cross_check = p.cross_check
+    with pkg.Group(p, n_devices=1) as g:
+        if mode.startswith("variant"):
+            import ctypes as C
+            h = C.c_void_p()
+            assert g._lib.lcm_group_handle(g._g, 0, C.byref(h)) == 0
+            assert g._lib.lcm_set_kernel_variant(h, int(mode[-1])) == 0
+        for f in range(fs.n_frames):
+            g.append(int(fs.ids[f]), fs.frame(f))
+        merged, offs = g.all_vs_all()
+        want, woffs = fast_all_vs_all(oracle, fs, op)
+        np.testing.assert_array_equal(offs.astype(np.int64), woffs)
+        np.testing.assert_array_equal(merged, want)
+        sc, ids = g.query_scores(fs.frame(20), 500)
+        pq = [20] * fs.n_frames
+        wq, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, pq, list(range(fs.n_frames)), op, n_threads=8)
+        np.testing.assert_array_equal(sc, wq)
