@@ -565,7 +565,10 @@ def main():
                          "(gfx950 corrections applied), NOT measured in this run",
                          "kernel": "k_score_rowlane<256,8,1,false> (argmin)" if argmin_api and not fused else "k_score_rowlane<256,8,0,false>",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes_launch,
-                         "note": "this path is VALU-bound by ~200x (0.016 algorithmic bytes per distance); see roofline_valu"},
+                         "note": "this path is VALU-bound by ~200x (0.016 algorithmic bytes per distance); see roofline_valu. "
+                                 "traffic = L2-to-fabric bytes incl. Infinity-Cache hits; the argmin kernel's re-scan re-reads 16 "
+                                 "of ~2000 rows per (query row, pair) and ~1/3 of those miss the XCD's L2 (1.3x algorithmic, at "
+                                 "0.6 % of HBM peak); the distance-only kernel moves 0.95x algorithmic"},
             "roofline_valu": {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
                               "frac": kern_rate / VALU_PEAK_DIST_PER_S,
                               "nominal_peak": VALU_NOMINAL_DIST_PER_S, "nominal_frac": kern_rate / VALU_NOMINAL_DIST_PER_S,
