@@ -69,7 +69,12 @@ typedef struct lcm_params {
     int32_t ratio;          /* good match: d <= max(ratio*min_d, dist_floor)      README.md:117 */
     int32_t dist_floor;     /* README states no floor -> 0 */
     int32_t min_matches;    /* loop needs good_count >= min_matches               README.md:124 */
-    int32_t min_gap;        /* compare only frames with cur_id - id >= min_gap    README.md:122, hpp:31 */
+    int32_t min_gap;        /* compare only frames with cur_id - id >= min_gap    README.md:122, hpp:31.
+                             * The gap is taken on frame IDS, not on storage positions: pass the processed-frame
+                             * counter as id (as processFrame's callers do), or scale min_gap, when ids are sparse
+                             * (e.g. raw video frame numbers with frame_skip = 3).  The tree's only executed
+                             * analogue, src/main.cpp:1374-1379, is positional over keyframe indices; the two readings
+                             * coincide for dense ids.  Part of what "parity unpinned" covers. */
     double  sim_threshold;  /* loop needs similarity > sim_threshold (strict)     README.md:123 */
     int32_t cross_check;    /* BFMatcher crossCheck (src/main.cpp:517 passes false): 0 = off (default);
                              * 1 = mutual nearest neighbours (recent OpenCV 4.x: the `sidx` test in batchDistance);
