@@ -1,0 +1,262 @@
+// lcm_bulk.cpp — the bulk all-vs-all search: plan (cached work list), launches, argmin / cross-check / matrix-core routing, fused loop test.
+// Part of liblcm_hip.so's host side (C ABI in include/lcm.h); shared state and helpers: lcm_internal.h.
+#include "lcm_internal.h"
+
+extern "C" {
+
+/* ---- bulk all-vs-all --------------------------------------------------------------------------------- */
+
+static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
+                   const int32_t* q_ids, int n_q_frames, int q_stride_rows,
+                   void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets,
+                   uint32_t* d_idx_sums = nullptr, const uint32_t* q_frame_of = nullptr,
+                   const int32_t* h_query_counts = nullptr) {
+    if (!h || !n_pairs) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    int rc = set_device(h); if (rc) return rc;
+    const bool self = (d_query_rows == nullptr);
+    std::vector<int32_t> self_ids;
+    if (self) {
+        n_q_frames = (int)h->frames.size();
+        self_ids.resize(n_q_frames);
+        for (int i = 0; i < n_q_frames; ++i) self_ids[i] = h->frames[i].id;
+        q_ids = self_ids.data();
+        q_stride_rows = h->stride_rows;
+    } else if (!d_query_counts || !q_ids || n_q_frames < 0 || q_stride_rows <= 0) {
+        return fail(LCM_ERR_INVALID_ARG, "external query set needs counts, ids and a stride");
+    }
+    if (q_stride_rows > lcm::MAX_FUSED_QUERY_ROWS && !self) return fail(LCM_ERR_CAPACITY, "query frames may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+
+    // ---- plan (cached while the database, the query-id list AND the query frames' row counts are unchanged)
+    // The row counts of an external query set live on the device and may change between calls with the same ids, and
+    // they pick the workgroup shape (a stale, smaller maximum would silently skip rows): they are fetched on every
+    // call (n_q_frames * 4 bytes) and are part of the key, as is the stride.
+    std::vector<int32_t> qc;
+    if (!self && n_q_frames > 0) {
+        qc.resize((size_t)n_q_frames);
+        if (h_query_counts) {            // the caller (lcm_group_*) already knows them on the host
+            memcpy(qc.data(), h_query_counts, sizeof(int32_t) * (size_t)n_q_frames);
+        } else {
+            HIP_TRY(hipMemcpyAsync(qc.data(), d_query_counts, sizeof(int32_t) * (size_t)n_q_frames, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        for (int c = 0; c < n_q_frames; ++c)
+            if (qc[c] < 0 || qc[c] > q_stride_rows) return fail(LCM_ERR_INVALID_ARG, "query frame %d has %d rows, stride %d", c, qc[c], q_stride_rows);
+    }
+    uint64_t key = mix(mix(mix(0x1234, (uint64_t)h->frames.size()), (uint64_t)n_q_frames), (uint64_t)h->params.min_gap);
+    key = mix(mix(key, self ? 1 : 2), (uint64_t)q_stride_rows);
+    key = mix(key, h->db_generation);
+    for (int i = 0; i < n_q_frames; ++i) key = mix(key, (uint64_t)(uint32_t)q_ids[i]);
+    if (q_frame_of) for (int i = 0; i < n_q_frames; ++i) key = mix(key, 0x51ull + q_frame_of[i]);
+    for (int32_t c : qc) key = mix(key, (uint64_t)(uint32_t)c);
+    if (!h->frames.empty()) key = mix(mix(key, (uint64_t)h->frames.front().id), (uint64_t)h->frames.back().id);
+    if (key == 0) key = 1;
+    Plan& P = h->plan;
+    if (P.key != key) {
+        P.key = 0;                        // a failed rebuild must not leave a half-built plan behind the old key
+        P.items.clear();
+        P.offsets.assign((size_t)n_q_frames + 1, 0);
+        size_t total = 0;
+        for (int c = 0; c < n_q_frames; ++c) { P.offsets[c] = total; total += (size_t)eligible_prefix(h, q_ids[c], h->params.min_gap); }
+        P.offsets[n_q_frames] = total;
+        if (total > 0xFFFFFFFFull) return fail(LCM_ERR_CAPACITY, "more than 2^32 pairs in one call");
+        const int chunk = pick_chunk(h, total);
+        P.distances = 0; P.algo_bytes = 0; P.max_q_rows = 0;
+        // prefix sums of stored row counts for the distance / byte accounting
+        std::vector<uint64_t> pre(h->frames.size() + 1, 0);
+        for (size_t s = 0; s < h->frames.size(); ++s) pre[s + 1] = pre[s] + (uint64_t)h->frames[s].n;
+        std::vector<int32_t> qn;
+        if (self) { qn.resize(n_q_frames); for (int i = 0; i < n_q_frames; ++i) qn[i] = h->frames[i].n; }
+        // heaviest query frames first so the tail of the launch is made of short items
+        for (int c = n_q_frames - 1; c >= 0; --c) {
+            const int e = (int)(P.offsets[c + 1] - P.offsets[c]);
+            for (int b = 0; b < e; b += chunk)
+                P.items.push_back({q_frame_of ? q_frame_of[c] : (uint32_t)c, (uint32_t)b, (uint32_t)std::min(chunk, e - b), (uint32_t)(P.offsets[c] + b)});
+            if (self && e > 0) {
+                P.distances += (uint64_t)qn[c] * pre[e];
+                P.algo_bytes += pre[e] * 32 + (uint64_t)qn[c] * 32 + 8ull * e;
+                P.max_q_rows = std::max(P.max_q_rows, (int)qn[c]);
+            }
+        }
+        if (!self) {
+            for (int c = 0; c < n_q_frames; ++c) {
+                const int e = (int)(P.offsets[c + 1] - P.offsets[c]);
+                if (e > 0) {
+                    P.distances += (uint64_t)qc[c] * pre[e];
+                    P.algo_bytes += pre[e] * 32 + (uint64_t)qc[c] * 32 + 8ull * e;
+                    P.max_q_rows = std::max(P.max_q_rows, (int)qc[c]);
+                }
+            }
+        }
+        if (P.max_q_rows > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "query frames may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+        P.n_pairs = total;
+        if (!P.items.empty()) {
+            rc = ensure_dev(P.d_items, P.d_items_cap, P.items.size()); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(P.d_items, P.items.data(), sizeof(lcm::WorkItem) * P.items.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        P.key = key;
+    }
+    *n_pairs = P.n_pairs;
+    if (pair_offsets) memcpy(pair_offsets, P.offsets.data(), sizeof(size_t) * ((size_t)n_q_frames + 1));
+    if (!d_scores) return LCM_OK;       // sizing call
+    if (scores_cap < P.n_pairs) return fail(LCM_ERR_CAPACITY, "scores buffer holds %zu records, need %zu", scores_cap, P.n_pairs);
+    if (P.n_pairs == 0) return LCM_OK;
+
+    rc = wait_db(h); if (rc) return rc;
+    if (h->params.cross_check) {
+        // BFMatcher crossCheck: every pair is matched in both directions and folded on the device
+        std::vector<uint32_t> row0((size_t)n_q_frames);
+        std::vector<int> nqv((size_t)n_q_frames), ev((size_t)n_q_frames);
+        const uint8_t* qbase = h->d_rows;
+        uint32_t pitch = (uint32_t)h->stride_rows;
+        if (!self) {
+            // the caller's rows carry no train-role padding: work on a padded copy
+            pitch = (uint32_t)(padded_rows(q_stride_rows) + 2 * ROW_PAD);
+            uint32_t n_slots = 0;
+            for (int c = 0; c < n_q_frames; ++c) n_slots = std::max(n_slots, (q_frame_of ? q_frame_of[c] : (uint32_t)c) + 1);
+            rc = ensure_dev(h->d_xq, h->d_xq_bytes, (size_t)n_slots * pitch * LCM_DESC_BYTES, ARENA_SLACK); if (rc) return rc;
+            HIP_TRY(hipMemcpy2DAsync(h->d_xq, (size_t)pitch * LCM_DESC_BYTES, d_query_rows, (size_t)q_stride_rows * LCM_DESC_BYTES,
+                                     (size_t)q_stride_rows * LCM_DESC_BYTES, n_slots, hipMemcpyDeviceToDevice, h->stream));
+            hipError_t e = lcm::launch_pad_rows((uint32_t*)h->d_xq, d_query_counts, pitch, n_slots, h->stream);
+            if (e != hipSuccess) return fail(LCM_ERR_HIP, "pad kernel launch failed: %s", hipGetErrorString(e));
+            qbase = h->d_xq;
+        }
+        for (int c = 0; c < n_q_frames; ++c) {
+            row0[(size_t)c] = (q_frame_of ? q_frame_of[c] : (uint32_t)c) * pitch;
+            nqv[(size_t)c] = self ? h->frames[(size_t)c].n : qc[(size_t)c];
+            ev[(size_t)c] = (int)(P.offsets[(size_t)c + 1] - P.offsets[(size_t)c]);
+        }
+        return cross_score_prefixes(h, qbase, row0.data(), nqv.data(), ev.data(), n_q_frames, (lcm_score*)d_scores, d_idx_sums);
+    }
+    if ((h->variant == 4 || h->variant == 5) && !d_idx_sums) {
+        std::vector<int> nqv((size_t)n_q_frames);
+        for (int c = 0; c < n_q_frames; ++c) nqv[(size_t)c] = self ? h->frames[(size_t)c].n : qc[(size_t)c];
+        return mfma_bulk(h, self, self ? h->d_rows : (const uint8_t*)d_query_rows, d_query_counts,
+                         (uint32_t)(self ? h->stride_rows : q_stride_rows), q_frame_of, nqv.data(), n_q_frames, P.offsets, (lcm_score*)d_scores);
+    }
+    lcm::ScoreArgs a{};
+    a.q_rows = self ? (const uint32_t*)h->d_rows : (const uint32_t*)d_query_rows;
+    a.q_counts = self ? h->d_counts : d_query_counts;
+    a.q_stride_words = (uint32_t)q_stride_rows * LCM_DESC_WORDS;
+    a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
+    a.items = P.d_items; a.scores = d_scores; a.keys = nullptr; a.keys_stride = 0;
+    a.idx_sums = d_idx_sums;             // non-NULL: the argmin kernel (variant 1) runs whatever the handle's variant
+    a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
+    const int variant = d_idx_sums ? 1 : h->variant;
+    // Very large searches go out as several launches (<= 2^20 work items, a few seconds each): no single kernel runs
+    // long enough to meet a compute-queue timeout, and the stream stays responsive.
+    constexpr size_t MAX_ITEMS_PER_LAUNCH = 1u << 20;
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    uint32_t launches = 0, biggest = 0;
+    for (size_t first = 0; first < P.items.size(); first += MAX_ITEMS_PER_LAUNCH) {
+        const uint32_t n = (uint32_t)std::min(MAX_ITEMS_PER_LAUNCH, P.items.size() - first);
+        a.items = P.d_items + first;
+        hipError_t e = lcm::launch_score(a, n, P.max_q_rows, false, variant, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        ++launches; biggest = std::max(biggest, n);
+    }
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    h->info_pending = true;
+    h->info.launches = launches; h->info.workgroups = biggest;
+    h->info.pairs = P.n_pairs; h->info.distances = P.distances; h->info.algo_bytes = P.algo_bytes;
+    return LCM_OK;
+}
+
+}  // extern "C"
+
+// the same search for the other translation units (lcm_group.cpp): index map + host-side row counts
+namespace lcm {
+int all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids,
+               int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, size_t* n_pairs,
+               size_t* pair_offsets, uint32_t* d_idx_sums, const uint32_t* q_frame_of, const int32_t* h_query_counts) {
+    return guarded([&] { return all_vs_all_impl(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, d_scores,
+                                                scores_cap, n_pairs, pair_offsets, d_idx_sums, q_frame_of, h_query_counts); });
+}
+}  // namespace lcm
+
+extern "C" {
+
+// Bulk loop search with the loop test fused on the device: all-vs-all scores stay in device memory, a second tiny
+// kernel applies README.md:123-126 per pair and compacts the candidates; only those cross PCIe.
+static int all_vs_all_loops_impl(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts,
+                         const int32_t* q_ids, const int32_t* q_keypoints, int n_q_frames, int q_stride_rows,
+                         lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out) {
+    if (!h || !n_out) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    *n_out = 0;
+    int rc = set_device(h); if (rc) return rc;
+    const bool self = (d_query_rows == nullptr);
+    size_t n_pairs = 0;
+    rc = lcm_all_vs_all(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, nullptr, 0, &n_pairs, nullptr);
+    if (rc) return rc;
+    if (n_pairs_out) *n_pairs_out = n_pairs;
+    h->bulk_scores_valid = 0;
+    if (n_pairs == 0) return LCM_OK;
+    rc = ensure_dev(h->d_bulk_scores, h->d_bulk_scores_n, n_pairs); if (rc) return rc;
+    rc = lcm_all_vs_all(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, h->d_bulk_scores, n_pairs, &n_pairs, nullptr);
+    if (rc) return rc;
+    const Plan& P = h->plan;
+    const int nq = self ? (int)h->frames.size() : n_q_frames;
+    const int ns = (int)h->frames.size();
+    // metadata the loop test needs, as one upload: offsets | q_ids | q_kp | db_ids | db_kp
+    std::vector<int32_t> meta((size_t)(nq + 1) + 2 * (size_t)nq + 2 * (size_t)ns);
+    int32_t* m_off = meta.data();
+    int32_t* m_qid = m_off + (nq + 1);
+    int32_t* m_qkp = m_qid + nq;
+    int32_t* m_did = m_qkp + nq;
+    int32_t* m_dkp = m_did + ns;
+    for (int c = 0; c <= nq; ++c) m_off[c] = (int32_t)(uint32_t)P.offsets[c];
+    std::vector<int32_t> qc;
+    if (!self && !q_keypoints) {           // external query set without keypoint counts: rows == keypoints (ORB)
+        qc.resize((size_t)nq);
+        HIP_TRY(hipMemcpy(qc.data(), d_query_counts, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
+    }
+    for (int c = 0; c < nq; ++c) {
+        m_qid[c] = self ? h->frames[c].id : q_ids[c];
+        m_qkp[c] = self ? h->frames[c].n_kp : (q_keypoints ? q_keypoints[c] : qc[c]);
+    }
+    for (int s = 0; s < ns; ++s) { m_did[s] = h->frames[s].id; m_dkp[s] = h->frames[s].n_kp; }
+    const size_t n_blocks = (n_pairs + 255) / 256;
+    rc = ensure_dev(h->d_meta, h->d_meta_n, meta.size() + 4 + n_blocks); if (rc) return rc;
+    const size_t dev_cap = std::max<size_t>(std::min<size_t>(cap, n_pairs), 1);
+    rc = ensure_dev(h->d_cands, h->d_cands_n, dev_cap); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_meta, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice, h->stream));
+    uint32_t* d_counter = reinterpret_cast<uint32_t*>(h->d_meta + meta.size());
+    HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), h->stream));
+    lcm::LoopTestArgs a{};
+    a.scores = h->d_bulk_scores;
+    a.offsets = reinterpret_cast<const uint32_t*>(h->d_meta);
+    a.q_ids = h->d_meta + (nq + 1); a.q_kp = a.q_ids + nq; a.db_ids = a.q_kp + nq; a.db_kp = a.db_ids + ns;
+    a.out = h->d_cands; a.counter = d_counter;
+    a.block_counts = d_counter + 4;
+    a.n_q = (uint32_t)nq; a.n_pairs = (uint32_t)n_pairs; a.cap = (uint32_t)dev_cap;
+    a.min_matches = h->params.min_matches; a.sim_threshold = h->params.sim_threshold;
+    HIP_TRY(hipEventRecord(h->ev_aux_start, h->stream));
+    hipError_t e = lcm::launch_loop_test(a, h->stream);
+    if (e != hipSuccess) return fail(LCM_ERR_HIP, "loop-test kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(h->ev_aux_stop, h->stream));
+    h->aux_pending = true;
+    h->bulk_scores_valid = n_pairs;
+    uint32_t found = 0;
+    HIP_TRY(hipMemcpyAsync(&found, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *n_out = found;
+    if (found > cap || !out) return found ? fail(LCM_ERR_CAPACITY, "%u loop candidates but room for %zu", found, cap) : LCM_OK;
+    // the device compacted them in pair order = (current id, matched id) ascending: nothing to sort
+    if (found) HIP_TRY(hipMemcpy(out, h->d_cands, sizeof(lcm_loop_candidate) * found, hipMemcpyDeviceToHost));
+    return LCM_OK;
+}
+
+/* ---- exported entry points, behind the exception guard ---- */
+
+int lcm_all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids, int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, size_t* n_pairs, size_t* pair_offsets) {
+    return guarded([&] { return all_vs_all_impl(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, d_scores, scores_cap, n_pairs, pair_offsets); });
+}
+int lcm_all_vs_all_argmin(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids, int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, void* d_index_sums, size_t* n_pairs, size_t* pair_offsets) {
+    if (d_scores && !d_index_sums) return fail(LCM_ERR_INVALID_ARG, "d_index_sums is NULL");
+    return guarded([&] { return all_vs_all_impl(h, d_query_rows, d_query_counts, q_ids, n_q_frames, q_stride_rows, d_scores, scores_cap, n_pairs, pair_offsets, (uint32_t*)d_index_sums); });
+}
+int lcm_all_vs_all_loops(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids, const int32_t* q_keypoints, int n_q_frames, int q_stride_rows, lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out) {
+    return guarded([&] { return all_vs_all_loops_impl(h, d_query_rows, d_query_counts, q_ids, q_keypoints, n_q_frames, q_stride_rows, out, cap, n_out, n_pairs_out); });
+}
+
+}  // extern "C"

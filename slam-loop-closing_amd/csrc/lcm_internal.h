@@ -1,5 +1,9 @@
-// lcm_internal.h — shared between the translation units of liblcm_hip.so (lcm_api.cpp, lcm_group.cpp): the handle,
-// its helpers and the error plumbing.  Not installed; the public surface is include/lcm.h.
+// lcm_internal.h — shared between the translation units of liblcm_hip.so's host side:
+//   lcm_api.cpp        handle lifetime, parameters, the device database (append, snapshot), launch info, scratch helpers
+//   lcm_pair.cpp       pair mode / match lists        lcm_online.cpp   online queries (single, micro-batch), detectLoops
+//   lcm_bulk.cpp       bulk all-vs-all, fused loops   lcm_cross.cpp    cross_check scoring
+//   lcm_mfma_host.cpp  opt-in matrix-core variants    lcm_group.cpp    multi-GPU group (RCCL)
+// Not installed; the public surface is include/lcm.h.
 #pragma once
 #include "../../include/lcm.h"
 
@@ -48,9 +52,14 @@ int guarded(F&& f) noexcept {
 constexpr int ROW_PAD = 4;            // stored rows are padded to a multiple of 4 with copies of the last row
 constexpr size_t ARENA_SLACK = 512;   // the kernel prefetches up to 4 rows past a frame's padded end
 constexpr int DEFAULT_MAX_DESC = 2000;  // ORB nfeatures of the reference (README.md:114)
-constexpr int STAGE_BUFS = 2;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int padded_rows(int n) { return round_up(n, ROW_PAD); }   // rows [n, round_up(n,4)) of a stored frame repeat row n-1
+inline uint64_t mix(uint64_t h, uint64_t v) { return h ^ (v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2)); }
+
+}  // namespace
+
+namespace lcm {
 
 struct FrameMeta {
     int32_t id;
@@ -59,6 +68,7 @@ struct FrameMeta {
 };
 
 constexpr int QUERY_SLOTS = 4;    // online queries that may be in flight at once (lcm_query_submit / _collect)
+constexpr int STAGE_BUFS = 2;
 
 struct QuerySlot {                // everything one in-flight online query owns
     bool busy = false;
@@ -90,7 +100,11 @@ struct Plan {            // cached work list of one bulk call shape
     int max_q_rows = 0;
 };
 
-}  // namespace
+}  // namespace lcm
+
+using lcm::FrameMeta;
+using lcm::Plan;
+using lcm::QuerySlot;
 
 struct lcm_handle {
     lcm_params params;
@@ -115,9 +129,9 @@ struct lcm_handle {
     bool pending_copy = false;
 
     // pinned staging ring for streaming appends
-    uint8_t* h_stage[STAGE_BUFS] = {nullptr, nullptr};
+    uint8_t* h_stage[lcm::STAGE_BUFS] = {nullptr, nullptr};
     size_t h_stage_bytes = 0;
-    hipEvent_t stage_done[STAGE_BUFS] = {nullptr, nullptr};
+    hipEvent_t stage_done[lcm::STAGE_BUFS] = {nullptr, nullptr};
     int32_t* h_counts = nullptr;       // pinned mirror of d_counts (source of the 4-byte async copies)
     int h_counts_cap = 0;
     int stage_next = 0;
@@ -139,7 +153,7 @@ struct lcm_handle {
     int32_t* d_meta = nullptr; size_t d_meta_n = 0;
     lcm_loop_candidate* d_cands = nullptr; size_t d_cands_n = 0;
 
-    QuerySlot qslots[QUERY_SLOTS];
+    QuerySlot qslots[lcm::QUERY_SLOTS];
     lcm_online_stats online{};         // totals over collected online queries (lcm_online_stats_read)
     uint64_t db_generation = 1;        // bumped whenever stored frames are dropped (lcm_db_clear / lcm_db_load)
     Plan plan;
@@ -175,6 +189,20 @@ int ensure_pinned(T*& p, size_t& have, size_t need) {
 }  // namespace
 
 namespace lcm {
+// ---- lcm_api.cpp
+int set_device(const lcm_handle* h);
+int wait_db(lcm_handle* h);            // make the match stream see every append issued so far
+int eligible_prefix(const lcm_handle* h, int query_id, int gap);   // eligible stored slots are a prefix: its length
+int pick_chunk(const lcm_handle* h, size_t total_pairs);
+int launch_and_time(lcm_handle* h, const ScoreArgs& a, uint32_t n_items, int max_q_rows, bool write_keys);
+// ---- lcm_cross.cpp: cross_check scoring of "query c against stored slots [0, elig[c])", records in (query, slot) order
+int cross_score_prefixes(lcm_handle* h, const uint8_t* d_qbase, const uint32_t* q_row0, const int* nq, const int* elig,
+                         int n_q, lcm_score* d_scores, uint32_t* d_idx_sums);
+// ---- lcm_mfma_host.cpp: opt-in matrix-core variants 4 / 5
+int mfma_online(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int pitch_rows, int B, const int* nq, const int* elig);
+int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int32_t* d_q_counts, uint32_t q_pitch_rows,
+              const uint32_t* q_frame_of, const int* nqv, int n_q, const std::vector<size_t>& offsets, lcm_score* d_scores);
+// ---- lcm_bulk.cpp
 // Bulk search behind lcm_all_vs_all / lcm_all_vs_all_argmin.  q_frame_of (optional, n_q_frames entries): query frame c
 // lives at index q_frame_of[c] of d_query_rows / d_query_counts instead of index c (the group's rank-major gathered
 // query buffer).  h_query_counts (optional, host, indexed by c) spares the device read of the row counts.
@@ -183,3 +211,16 @@ int all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_c
                int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, size_t* n_pairs,
                size_t* pair_offsets, uint32_t* d_idx_sums, const uint32_t* q_frame_of, const int32_t* h_query_counts);
 }  // namespace lcm
+
+namespace {
+using lcm::cross_score_prefixes;
+using lcm::eligible_prefix;
+using lcm::launch_and_time;
+using lcm::mfma_bulk;
+using lcm::mfma_online;
+using lcm::pick_chunk;
+using lcm::QUERY_SLOTS;
+using lcm::set_device;
+using lcm::STAGE_BUFS;
+using lcm::wait_db;
+}  // namespace
