@@ -74,3 +74,19 @@ def test_stream_mode_contract():
     assert rf["bound"] == "hbm" and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["launches"] >= 150 // 8 and d["roofline_valu"]["achieved"] > 0 and 0 < d["device_busy_frac"] <= 1.0
     assert d["cpu_baseline"]["gpu_vs_cpu_sample_mismatches"] == 0 and d["cpu_baseline"]["kind"] == "port"
+
+
+def test_three_rank_stream_rehearsal_gloo():
+    """The N > 1 form of --mode stream (configs[4] shape: every rank sees every frame, appends the ones it owns, scores
+    are gathered once per step) with 3 gloo ranks sharing the box's GPU; the merged records are checked against the
+    pair count of the whole search."""
+    port = free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "3", "--mode", "stream",
+                        "--frames", "130", "--desc", "400", "--steps", "1", "--warmup", "1", "--backend", "gloo",
+                        "--cpu-seconds", "0", "--stream-batch", "8"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 3 and d["config"]["sharding"] == "cyclic by frame" and d["config"]["stream_batch"] == 8
+    assert d["config"]["pairs_per_step"] == (130 - 30) * (130 - 29) // 2
+    assert d["value"] > 0 and d["roofline"]["launches"] > 0
