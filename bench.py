@@ -290,6 +290,8 @@ def main():
     ap.add_argument("--variant", type=int, default=1, help="1 (default): the ARGMIN kernel through lcm_all_vs_all_argmin — "
                     "per-query min AND first-minimum train index, per-pair index checksum written; 0: distance-only kernel; "
                     "2 / 3: the train-row-per-lane mapping (A/B measurement)")
+    ap.add_argument("--packed", type=int, default=-1, help="bulk search with query rows packed into full 2048-row workgroups "
+                    "(LCM_TUNE_PACKED): -1 automatic (default), 0 never, 1 always")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget; 0 disables")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores this process may use")
     ap.add_argument("--mode", default="batch", help="batch (default: one all-vs-all pass per step) | stream (online: "
@@ -374,6 +376,7 @@ def main():
     m = pkg.Matcher(p, device=local_rank, stream=stream.cuda_stream)
     argmin_api = (args.variant == 1)                 # headline: north_star's "per-query min/argmin + match count"
     m.set_kernel_variant(0 if argmin_api else args.variant)
+    m.set_tuning(pkg.capi.TUNE_PACKED, args.packed)
     owned = pkg.sharding.owned_positions(n_frames, rank, world)
     m.reserve(len(owned), n_desc)
     frame_bytes = fs.stride_rows * 32

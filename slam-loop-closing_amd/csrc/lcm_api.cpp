@@ -201,7 +201,7 @@ void lcm_destroy(lcm_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     (void)hipFree(h->d_rows); (void)hipFree(h->d_counts);
-    (void)hipFree(h->d_keys); (void)hipFree(h->plan.d_items);
+    (void)hipFree(h->d_keys); (void)hipFree(h->plan.d_items); (void)hipFree(h->plan.d_pk_tab);
     (void)hipFree(h->d_bulk_scores); (void)hipFree(h->d_meta); (void)hipFree(h->d_cands);
     for (QuerySlot& q : h->qslots) {
         (void)hipFree(q.d_query); (void)hipFree(q.d_scores); (void)hipFree(q.d_dist); (void)hipFree(q.d_meta);
@@ -273,6 +273,9 @@ int lcm_set_tuning(lcm_handle* h, int knob, int value) {
             if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4)
                 return fail(LCM_ERR_INVALID_ARG, "online split must be -1 (automatic), 0 (off), 1, 2 or 4 rows per lane");
             h->tune_online_split = value; return LCM_OK;
+        case LCM_TUNE_PACKED:
+            if (value < -1 || value > 1) return fail(LCM_ERR_INVALID_ARG, "packed rows must be -1 (automatic), 0 (off) or 1 (on)");
+            h->tune_packed = value; h->plan.key = 0; return LCM_OK;
         default: return fail(LCM_ERR_INVALID_ARG, "unknown tuning knob %d", knob);
     }
 }

@@ -98,6 +98,15 @@ struct Plan {            // cached work list of one bulk call shape
     size_t n_pairs = 0;
     uint64_t distances = 0, algo_bytes = 0;
     int max_q_rows = 0;
+    // PACKED form (lcm_kernels.h, ScoreArgs::pk_*): `items` then holds (column, slot run) items chunk by chunk and
+    // d_pk_tab = [pair offsets (n_q + 1) | query row counts (n_q) | per chunk: vstart (n_pos + 1), qframe, elig, pairs]
+    struct PackedChunk { uint32_t item0, n_items, tab0, n_pos, pair_base, n_pairs; };
+    bool packed = false;
+    std::vector<PackedChunk> pk_chunks;
+    uint32_t* d_pk_tab = nullptr;
+    size_t d_pk_tab_n = 0;
+    size_t pk_max_pairs = 0;        // largest chunk: sizes the per-row scratch (8 KB per pair)
+    uint32_t pk_n_q = 0;
 };
 
 }  // namespace lcm
@@ -119,6 +128,7 @@ struct lcm_handle {
     int variant = 0;
     int tune_item_slots = 0;           // 0 = automatic (pick_chunk)
     int tune_online_split = -1;        // -1 = automatic (enqueue_query)
+    int tune_packed = -1;              // -1 = automatic (bulk plan: when it saves lane slots), 0 = never, 1 = always
 
     // database arena
     uint8_t* d_rows = nullptr;

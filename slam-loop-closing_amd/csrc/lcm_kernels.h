@@ -54,6 +54,18 @@ struct ScoreArgs {
     // of bat_nq[b] rows stored at chunk index b * imp_chunks of q_rows, scored against stored slots [0, bat_elig[b]);
     // its workgroups are [bat_wg[b], bat_wg[b + 1]) and its records start at pair index bat_pair[b].  imp_chunks,
     // imp_chunk_rows and imp_spi are shared by the whole batch.
+    // PACKED bulk mode (launch_score_packed): the query rows of consecutive query frames form one virtual row space cut
+    // into 2048-row workgroups, so a 2000-row frame no longer leaves 48 of 2048 lane slots idle.  Work item: q_frame =
+    // workgroup index w in that space (virtual rows [2048 w, 2048 w + 2048)), slots as usual.  Per query frame c of the
+    // chunk (pk_n of them): pk_vstart[c] = its first virtual row (pk_vstart[pk_n] = total), pk_qframe[c] = its index in
+    // q_rows, pk_elig[c] = eligible stored slots, pk_pairs[c] = its first pair in pk_dist.  Output: the best distance
+    // (ARGMIN: packed key) of every (pair, query row) -> pk_dist[pair * 2048 + row]; launch_finalize_bulk folds them.
+    const uint32_t* pk_vstart;
+    const uint32_t* pk_qframe;
+    const uint32_t* pk_elig;
+    const uint32_t* pk_pairs;
+    uint32_t*       pk_dist;
+    uint32_t        pk_n;
     uint32_t        imp_nbatch;
     uint32_t        bat_wg[MAX_QUERY_BATCH + 1];
     uint32_t        bat_pair[MAX_QUERY_BATCH + 1];
@@ -65,6 +77,8 @@ struct ScoreArgs {
 // frame referenced (<= MAX_FUSED_QUERY_ROWS).  variant: 0 = row-per-lane/scalar-broadcast (default).
 hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,
                         hipStream_t st);
+// PACKED bulk mode (see ScoreArgs::pk_*): 256-thread workgroups of 8 rows per lane; argmin = group keys + re-scan.
+hipError_t launch_score_packed(const ScoreArgs& a, uint32_t n_items, bool argmin, hipStream_t st);
 
 // Split mode (short databases): chunks of 256 * qpt query rows per workgroup write per-row best distances into
 // a.keys; launch_finalize folds each pair's rows into its lcm_score record.
@@ -187,6 +201,8 @@ hipError_t launch_score_mfma_fp4(const MfmaArgs& a, uint32_t n_items, hipStream_
 // Pair p (global index, pair_base <= p < pair_base + n_pairs) belongs to query c = last c with offsets[c] <= p and is
 // stored slot p - offsets[c]; folds dist[(p - pair_base) * 2048 + r], r < nq[c], into the pair's score record.
 struct FinalizeBulkArgs {
+    int32_t         key_shift;     // 0: dist holds distances; KEY_SHIFT: packed keys dist << 22 | train row
+    uint32_t*       idx_sums;      // optional (keys): per pair, sum of the good matches' train rows mod 2^32
     const uint32_t* dist;
     const uint32_t* offsets;       // n_q + 1
     const int32_t*  nq;            // n_q query row counts

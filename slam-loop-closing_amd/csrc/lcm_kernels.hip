@@ -154,7 +154,15 @@ constexpr int ARGMIN_GROUP = 16;      // train rows per (dist, group) key; a mul
 // hide behind the other waves); 2 = argmin by a packed key per distance (v_lshl_or_b32 per distance, +8 % VALU, no
 // re-scan: the pair mode, where a launch is a few dozen workgroups and the re-scan's ~250 dependent loads per lane
 // would be most of its latency).
-template <int THREADS, int QPT, int ARGMIN_MODE, bool WRITE_KEYS>
+//
+// PACKED (bulk search, 256 x 8 only): the workgroup owns 2048 consecutive rows of a VIRTUAL row space in which the
+// query frames of a chunk follow one another without gaps (ScoreArgs::pk_*), so a 2000-row ORB frame no longer leaves
+// 48 of the 2048 lane slots idle (measured worth: 2.5 %, profiles/r02_idle_lanes.txt).  A lane's 8 rows may then
+// belong to different query frames: each (lane, j) keeps `packed position << 11 | row in its frame` in a lane-private
+// LDS word, the per-pair reductions move to k_finalize_bulk, and the epilogue is 8 stores per lane per stored frame
+// (best distance, or best key in the argmin mode) — skipped where the stored frame is not eligible for that row's
+// query frame (the frames are packed by descending eligibility, so that is the last few slots of a column only).
+template <int THREADS, int QPT, int ARGMIN_MODE, bool WRITE_KEYS, bool PACKED = false>
 __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
     // ARGMIN_MODE = 0 with WRITE_KEYS = true writes the best DISTANCE per query row (split mode, see k_finalize_pairs)
     constexpr bool ARGMIN = ARGMIN_MODE != 0;
@@ -165,6 +173,7 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
     __shared__ uint32_t red_sum[2];
     __shared__ uint32_t red_idx[2];
     __shared__ uint32_t lane_key[GROUPED ? THREADS * QPT : 1];
+    __shared__ uint32_t lane_meta[PACKED ? THREADS * QPT : 1];     // PACKED: packed position << 11 | row, 0xFFFFFFFF = idle
 
     const int tid = threadIdx.x;
     if (tid == 0) { red_min[0] = red_min[1] = 0xFFFFFFFFu; red_sum[0] = red_sum[1] = 0u; red_idx[0] = red_idx[1] = 0u; }
@@ -175,7 +184,11 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
     size_t q_word0;                            // first dword of this item's query rows in q_rows
     uint32_t pair_t_row = 0;
     int pair_nt = -1;                          // >= 0: pair mode (one train segment given by the item itself)
-    if (a.pair_items) {
+    if (PACKED) {                              // q_frame = column of the virtual row space, out_offset = its first packed position
+        it = a.items[blockIdx.x];
+        nq = (int)min((uint32_t)(THREADS * QPT), a.pk_vstart[a.pk_n] - it.q_frame * (uint32_t)(THREADS * QPT));
+        q_word0 = 0;
+    } else if (a.pair_items) {
         const PairItem pi = a.pair_items[blockIdx.x];
         it.q_frame = 0; it.slot_begin = 0; it.n_slots = 1; it.out_offset = pi.out_offset;
         nq = (int)(pi.nq_nt & 0xFFFu);
@@ -206,7 +219,26 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
     // ---- load this lane's query rows: row = j*THREADS + tid (consecutive lanes -> consecutive 32-byte rows)
     uint32_t q[QPT][8];
     auto valid = [&](int j) { return j * THREADS + tid < nq; };     // recomputed where needed: keeps VGPRs <= 80
-    {
+    if (PACKED) {
+        uint32_t c = it.out_offset;            // packed position that holds the column's first row; rows ascend with j
+        const uint32_t v0 = it.q_frame * (uint32_t)(THREADS * QPT);
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const uint32_t v = v0 + (uint32_t)(j * THREADS + tid);
+            uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
+            uint32_t meta = 0xFFFFFFFFu;
+            if (j * THREADS + tid < nq) {
+                while (a.pk_vstart[c + 1] <= v) ++c;                // v < pk_vstart[pk_n]: stops at c < pk_n
+                const uint32_t r = v - a.pk_vstart[c];
+                const uint4* qb = reinterpret_cast<const uint4*>(a.q_rows + (size_t)a.pk_qframe[c] * a.q_stride_words);
+                lo = qb[r * 2]; hi = qb[r * 2 + 1];
+                meta = (c << 11) | r;
+            }
+            lane_meta[j * THREADS + tid] = meta;
+            q[j][0] = lo.x; q[j][1] = lo.y; q[j][2] = lo.z; q[j][3] = lo.w;
+            q[j][4] = hi.x; q[j][5] = hi.y; q[j][6] = hi.z; q[j][7] = hi.w;
+        }
+    } else {
         const uint4* qbase = reinterpret_cast<const uint4*>(a.q_rows + q_word0);
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
@@ -297,6 +329,16 @@ __global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
             for (int j = 0; j < QPT; ++j) best[j] = lane_key[j * THREADS + tid];
         }
 
+        if (PACKED) {        // best distance / key of every (eligible pair, query row); k_finalize_bulk forms the records
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) {
+                const uint32_t meta = lane_meta[j * THREADS + tid];
+                if (meta == 0xFFFFFFFFu) continue;
+                const uint32_t c = meta >> 11, r = meta & 2047u;
+                if (slot < a.pk_elig[c]) a.pk_dist[((size_t)a.pk_pairs[c] + slot) * MAX_FUSED_QUERY_ROWS + r] = best[j];
+            }
+            continue;
+        }
         // ---- pair epilogue: min-of-mins, ratio filter count, one score record
         const size_t out = (size_t)it.out_offset + s;
         if (WRITE_KEYS) {
@@ -582,6 +624,13 @@ hipError_t launch_fold_pair_keys(const FoldArgs& a, uint32_t max_nq, hipStream_t
 hipError_t launch_finalize(const FinalizeArgs& a, uint32_t n_pairs, hipStream_t st) {
     if (n_pairs == 0) return hipSuccess;
     hipLaunchKernelGGL(k_finalize_pairs, dim3(n_pairs), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_packed(const ScoreArgs& a, uint32_t n_items, bool argmin, hipStream_t st) {
+    if (n_items == 0) return hipSuccess;
+    if (argmin) hipLaunchKernelGGL((k_score_rowlane<256, 8, 1, false, true>), dim3(n_items), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_score_rowlane<256, 8, 0, false, true>), dim3(n_items), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -236,7 +236,7 @@ hipError_t launch_score_mfma_fp4(const MfmaArgs& a, uint32_t n_items, hipStream_
 
 // ---- per-pair fold of the best distances ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a) {
-    __shared__ uint32_t red_min, red_sum;
+    __shared__ uint32_t red_min, red_sum, red_idx;
     const int tid = threadIdx.x;
     const uint32_t p = a.pair_base + blockIdx.x;
     uint32_t lo = 0, hi = a.n_q;                                // last c with offsets[c] <= p
@@ -246,18 +246,26 @@ __global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a) {
     }
     const int nq = a.nq[lo];
     const uint32_t slot = p - a.offsets[lo];
-    if (tid == 0) { red_min = 0xFFFFFFFFu; red_sum = 0u; }
+    if (tid == 0) { red_min = 0xFFFFFFFFu; red_sum = 0u; red_idx = 0u; }
     __syncthreads();
     const uint32_t* d = a.dist + (size_t)blockIdx.x * MAX_FUSED_QUERY_ROWS;
+    const int sh = a.key_shift;
+    const uint32_t idx_mask = sh ? ((1u << sh) - 1u) : 0u;
     uint32_t dmin = 0xFFFFFFFFu;
-    for (int r = tid; r < nq; r += 256) dmin = min(dmin, d[r]);
+    for (int r = tid; r < nq; r += 256) dmin = min(dmin, d[r] >> sh);
     atomicMin(&red_min, dmin);
     __syncthreads();
     dmin = red_min;
     const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
-    uint32_t cnt = 0;
-    for (int r = tid; r < nq; r += 256) cnt += d[r] <= thr ? 1u : 0u;
+    uint32_t cnt = 0, isum = 0;
+    for (int r = tid; r < nq; r += 256) {
+        const uint32_t v = d[r];
+        const bool good = (v >> sh) <= thr;
+        cnt += good ? 1u : 0u;
+        isum += good ? (v & idx_mask) : 0u;
+    }
     atomicAdd(&red_sum, cnt);
+    if (a.idx_sums) atomicAdd(&red_idx, isum);
     __syncthreads();
     if (tid == 0) {
         const int nt = a.db_counts[slot];
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a) {
         rec.x = empty ? 0u : red_sum;
         rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
         reinterpret_cast<uint2*>(a.scores)[p] = rec;
+        if (a.idx_sums) a.idx_sums[p] = empty ? 0u : red_idx;
     }
 }
 

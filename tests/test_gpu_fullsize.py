@@ -175,9 +175,10 @@ def test_search_larger_than_one_launch(pkg, oracle):
     p = pkg.default_params()
     p.min_gap = 30
 
-    def run(chunk):
+    def run(chunk, packed=0):
         with pkg.Matcher(p) as m:
             m.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, chunk)               # 0 = automatic
+            m.set_tuning(pkg.capi.TUNE_PACKED, packed)
             for f in range(fs.n_frames):
                 m.append(int(fs.ids[f]), fs.frame(f))
             n, offs = m.all_vs_all_plan()
@@ -195,6 +196,12 @@ def test_search_larger_than_one_launch(pkg, oracle):
     assert l1 == 1 and l2 == 2
     np.testing.assert_array_equal(one, many)
     np.testing.assert_array_equal(offs, offs2)
+    # the automatic plan packs these 256-row frames eight to a 2048-row workgroup (half the lane slots of the 64 x 8
+    # shape are idle otherwise); more than 2^20 pairs -> two chunks of (score, fold) launches
+    packed, offs3, l3 = run(0, -1)
+    assert l3 == 4
+    np.testing.assert_array_equal(one, packed)
+    np.testing.assert_array_equal(offs, offs3)
     rng = np.random.default_rng(3)
     qs = rng.integers(30, 1500, 300)
     ts = np.array([rng.integers(0, q - 29) for q in qs])

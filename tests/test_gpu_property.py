@@ -93,13 +93,15 @@ def test_bulk_and_online_paths_equal_oracle(matcher, oracle, db):
 
 
 @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(small_databases(), st.sampled_from([0, 1, 2]), st.sampled_from([0, 1, 4, 5]))
-def test_every_bulk_route_equals_oracle(matcher, oracle, db, cross, variant):
+@given(small_databases(), st.sampled_from([0, 1, 2]), st.sampled_from([0, 1, 4, 5]), st.sampled_from([-1, 1]))
+def test_every_bulk_route_equals_oracle(matcher, pkg, oracle, db, cross, variant, packed):
     """The round-2 routes through the same random ragged databases: lcm_all_vs_all_argmin (records + index checksum),
-    cross_check 0 / 1 / 2, kernel variants 0 / 1 / 4 / 5, micro-batched online queries, batched match lists."""
+    cross_check 0 / 1 / 2, kernel variants 0 / 1 / 4 / 5, the packed bulk form (forced: all frames of these small
+    databases share ONE 2048-row workgroup column), micro-batched online queries, batched match lists."""
     rows, counts, ids, gap = db
     matcher.set_params(min_gap=gap, min_matches=1, sim_threshold=0.0, cross_check=cross)
     matcher.set_kernel_variant(variant)
+    matcher.set_tuning(pkg.capi.TUNE_PACKED, packed)
     p = oracle.default_params(min_gap=gap, min_matches=1, sim_threshold=0.0, cross_check=cross)
     n_frames = len(counts)
     try:
@@ -147,5 +149,6 @@ def test_every_bulk_route_equals_oracle(matcher, oracle, db, cross, variant):
                 np.testing.assert_array_equal(got_l, om.astype(got_l.dtype))
     finally:
         matcher.set_kernel_variant(0)
+        matcher.set_tuning(pkg.capi.TUNE_PACKED, -1)
         matcher.set_params(min_gap=30, min_matches=50, sim_threshold=0.15, cross_check=0)
         matcher.clear()
