@@ -446,14 +446,27 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
-    info = m.launch_info()                                        # HIP events around the LAST step's kernel
-    kernel_ms.append(info.kernel_ms)
+    info = m.launch_info()                                        # HIP events around the LAST step's kernel(s)
+    # Packed route (the automatic choice for 2000-row frames): a step is the score kernel + the fold kernel
+    # (k_finalize_bulk).  kernel_ms covers both; the roofline is that of the DOMINANT kernel, so its own duration is
+    # kernel_ms - fold when the call is one chunk (aux_kernel_ms times the last chunk's fold by itself).
+    packed = (info.route == pkg.capi.ROUTE_PACKED)
+    one_chunk = packed and info.launches == 2
+    fold_ms = []
+
+    def dominant_ms(li):
+        if one_chunk and not fused:
+            fold_ms.append(li.aux_kernel_ms)
+            return li.kernel_ms - li.aux_kernel_ms
+        return li.kernel_ms
+
+    kernel_ms.append(dominant_ms(info))
     # a few more individually timed launches for a stable per-launch duration (outside the timed region)
     loop_test_ms = info.aux_kernel_ms if fused else None
     long_step = info.kernel_ms > 2000.0          # cfg3-sized steps: the timed region's own launches are evidence enough
     for _ in range(min(3, max(args.steps - 1, 0)) if not (fused or long_step) else 0):
         search((send if multi else scores).data_ptr(), cap if multi else n_local)
-        kernel_ms.append(m.launch_info().kernel_ms)
+        kernel_ms.append(dominant_ms(m.launch_info()))
     kern_ms = float(np.mean(kernel_ms))
 
     local_dist = int(info.distances)
@@ -543,7 +556,7 @@ def main():
             try:
                 t = json.load(open(tp))
                 if (t.get("workload") == wl and t.get("n_gpus") == world and t.get("frames") == n_frames
-                        and t.get("kernel_variant", 0) == args.variant and not fused):
+                        and t.get("kernel_variant", 0) == args.variant and bool(t.get("packed", False)) == packed and not fused):
                     traffic = t.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -566,12 +579,16 @@ def main():
                          "traffic_source": None if traffic is None else
                          "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command "
                          "(gfx950 corrections applied), NOT measured in this run",
-                         "kernel": "k_score_rowlane<256,8,1,false> (argmin)" if argmin_api and not fused else "k_score_rowlane<256,8,0,false>",
+                         "kernel": "k_score_rowlane<256, 8, %d, false, %s>%s" % (1 if argmin_api and not fused else 0, "true" if packed else "false",
+                                                                                  " (argmin)" if argmin_api and not fused else ""),
+                         "route": "packed: query rows of consecutive frames share full 2048-row workgroups; records formed by "
+                                  "k_finalize_bulk" if packed else "one workgroup per (query frame, run of stored frames)",
+                         "fold_kernel_ms": float(np.mean(fold_ms)) if fold_ms else None,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "note": "this path is VALU-bound by ~200x (0.016 algorithmic bytes per distance); see roofline_valu. "
                                  "traffic = L2-to-fabric bytes incl. Infinity-Cache hits; the argmin kernel's re-scan re-reads 16 "
-                                 "of ~2000 rows per (query row, pair) and ~1/3 of those miss the XCD's L2 (1.3x algorithmic, at "
-                                 "0.6 % of HBM peak); the distance-only kernel moves 0.95x algorithmic"},
+                                 "of ~2000 rows per (query row, pair) and ~1/3 of those miss the XCD's L2; the packed route adds "
+                                 "4 bytes written + read per (pair, query row) of scratch (8 KB per pair, < 1 % of HBM peak)"},
             "roofline_valu": {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
                               "frac": kern_rate / VALU_PEAK_DIST_PER_S,
                               "nominal_peak": VALU_NOMINAL_DIST_PER_S, "nominal_frac": kern_rate / VALU_NOMINAL_DIST_PER_S,

@@ -116,8 +116,15 @@ typedef struct lcm_launch_info {
     uint32_t launches;          /* kernel launches that made up the call */
     uint32_t workgroups;        /* workgroups of the (largest) launch */
     double   aux_kernel_ms;     /* device time of the call's follow-up kernel, 0 if none: k_loop_test of
-                                 * lcm_all_vs_all_loops */
+                                 * lcm_all_vs_all_loops; the (last chunk's) fold kernel of a packed bulk search */
+    uint32_t route;             /* which kernels served the call: lcm_route */
+    uint32_t reserved_;
 } lcm_launch_info;
+/* LCM_ROUTE_PLAIN: one workgroup per (query frame, run of stored frames), records formed in the kernel;
+ * LCM_ROUTE_PACKED: query rows of consecutive frames packed into full 2048-row workgroups + fold kernel (bulk);
+ * LCM_ROUTE_SPLIT: query frame cut into row chunks + fold kernel (online, short databases);
+ * LCM_ROUTE_MATRIX: opt-in matrix-core variants 4 / 5; LCM_ROUTE_CROSS: cross_check (two passes + combine). */
+typedef enum lcm_route { LCM_ROUTE_PLAIN = 0, LCM_ROUTE_PACKED = 1, LCM_ROUTE_SPLIT = 2, LCM_ROUTE_MATRIX = 3, LCM_ROUTE_CROSS = 4 } lcm_route;
 
 /* Totals over the online queries COLLECTED so far on a handle (single and batched): device time of their kernels from
  * HIP events on the launch stream, and the work they did — what a streaming run's roofline is computed from. */

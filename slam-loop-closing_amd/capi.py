@@ -48,7 +48,10 @@ class LoopCandidate(C.Structure):
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("pairs", C.c_uint64), ("distances", C.c_uint64),
                 ("algo_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32),
-                ("aux_kernel_ms", C.c_double)]
+                ("aux_kernel_ms", C.c_double), ("route", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
+ROUTE_PLAIN, ROUTE_PACKED, ROUTE_SPLIT, ROUTE_MATRIX, ROUTE_CROSS = range(5)      # lcm_route
 
 
 class OnlineStats(C.Structure):

@@ -67,6 +67,7 @@ int launch_and_time(lcm_handle* h, const ScoreArgs& a, uint32_t n_items, int max
     h->info_pending = true;
     h->info.launches = 1;
     h->info.workgroups = n_items;
+    h->info.route = LCM_ROUTE_PLAIN;
     return LCM_OK;
 }
 

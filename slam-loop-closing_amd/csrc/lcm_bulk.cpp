@@ -243,7 +243,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
         }
         HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
         h->info_pending = true;
-        h->info.launches = launches; h->info.workgroups = biggest;
+        h->info.launches = launches; h->info.workgroups = biggest; h->info.route = LCM_ROUTE_PACKED;
         h->info.pairs = P.n_pairs; h->info.distances = P.distances; h->info.algo_bytes = P.algo_bytes;
         return LCM_OK;
     }
@@ -261,7 +261,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     }
     HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
     h->info_pending = true;
-    h->info.launches = launches; h->info.workgroups = biggest;
+    h->info.launches = launches; h->info.workgroups = biggest; h->info.route = LCM_ROUTE_PLAIN;
     h->info.pairs = P.n_pairs; h->info.distances = P.distances; h->info.algo_bytes = P.algo_bytes;
     return LCM_OK;
 }

@@ -76,7 +76,7 @@ int cross_score_prefixes(lcm_handle* h, const uint8_t* d_qbase, const uint32_t* 
     { const int rc = flush(); if (rc) return rc; }
     HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
     h->info_pending = true;
-    h->info.launches = launches; h->info.workgroups = 0;
+    h->info.launches = launches; h->info.workgroups = 0; h->info.route = LCM_ROUTE_CROSS;
     h->info.pairs = pairs; h->info.distances = dist; h->info.algo_bytes = bytes;
     return LCM_OK;
 }

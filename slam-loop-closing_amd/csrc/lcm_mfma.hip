@@ -235,10 +235,14 @@ hipError_t launch_score_mfma_fp4(const MfmaArgs& a, uint32_t n_items, hipStream_
 }
 
 // ---- per-pair fold of the best distances ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a) {
-    __shared__ uint32_t red_min, red_sum, red_idx;
-    const int tid = threadIdx.x;
-    const uint32_t p = a.pair_base + blockIdx.x;
+// One WAVE per pair: a pair's <= 2048 per-row words are read once, 8 coalesced 16-byte loads per lane (1 KiB per wave
+// load), and stay in 32 registers for both passes (min-of-mins, then the ratio-filter count); the two wave reductions
+// are shuffles.  HBM/L2-bound: 4 B read per (pair, query row) + 8 (12) B written per pair.
+__global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a, uint32_t n_pairs) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t local = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (local >= n_pairs) return;                               // whole wave: no barrier follows
+    const uint32_t p = a.pair_base + local;
     uint32_t lo = 0, hi = a.n_q;                                // last c with offsets[c] <= p
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -246,41 +250,49 @@ __global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a) {
     }
     const int nq = a.nq[lo];
     const uint32_t slot = p - a.offsets[lo];
-    if (tid == 0) { red_min = 0xFFFFFFFFu; red_sum = 0u; red_idx = 0u; }
-    __syncthreads();
-    const uint32_t* d = a.dist + (size_t)blockIdx.x * MAX_FUSED_QUERY_ROWS;
+    const uint4* d = reinterpret_cast<const uint4*>(a.dist + (size_t)local * MAX_FUSED_QUERY_ROWS);
     const int sh = a.key_shift;
     const uint32_t idx_mask = sh ? ((1u << sh) - 1u) : 0u;
+    uint32_t v[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r0 = (i * 64 + lane) * 4;                     // rows r0 .. r0 + 3; rows >= nq hold stale words: masked
+        uint4 x = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (r0 < nq) x = d[i * 64 + lane];
+        v[4 * i + 0] = x.x;
+        v[4 * i + 1] = r0 + 1 < nq ? x.y : 0xFFFFFFFFu;
+        v[4 * i + 2] = r0 + 2 < nq ? x.z : 0xFFFFFFFFu;
+        v[4 * i + 3] = r0 + 3 < nq ? x.w : 0xFFFFFFFFu;
+    }
     uint32_t dmin = 0xFFFFFFFFu;
-    for (int r = tid; r < nq; r += 256) dmin = min(dmin, d[r] >> sh);
-    atomicMin(&red_min, dmin);
-    __syncthreads();
-    dmin = red_min;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) dmin = min(dmin, v[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : v[k] >> sh);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
     const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
     uint32_t cnt = 0, isum = 0;
-    for (int r = tid; r < nq; r += 256) {
-        const uint32_t v = d[r];
-        const bool good = (v >> sh) <= thr;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const bool good = v[k] != 0xFFFFFFFFu && (v[k] >> sh) <= thr;
         cnt += good ? 1u : 0u;
-        isum += good ? (v & idx_mask) : 0u;
+        isum += good ? (v[k] & idx_mask) : 0u;
     }
-    atomicAdd(&red_sum, cnt);
-    if (a.idx_sums) atomicAdd(&red_idx, isum);
-    __syncthreads();
-    if (tid == 0) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { cnt += (uint32_t)__shfl_xor((int)cnt, o, 64); isum += (uint32_t)__shfl_xor((int)isum, o, 64); }
+    if (lane == 0) {
         const int nt = a.db_counts[slot];
-        const bool empty = (nq <= 0) || (nt <= 0);
+        const bool empty = (nq <= 0) || (nt <= 0) || dmin == 0xFFFFFFFFu;
         uint2 rec;
-        rec.x = empty ? 0u : red_sum;
+        rec.x = empty ? 0u : cnt;
         rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
         reinterpret_cast<uint2*>(a.scores)[p] = rec;
-        if (a.idx_sums) a.idx_sums[p] = empty ? 0u : red_idx;
+        if (a.idx_sums) a.idx_sums[p] = empty ? 0u : isum;
     }
 }
 
 hipError_t launch_finalize_bulk(const FinalizeBulkArgs& a, uint32_t n_pairs, hipStream_t st) {
     if (n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_finalize_bulk, dim3(n_pairs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_finalize_bulk, dim3((n_pairs + 3) / 4), dim3(256), 0, st, a, n_pairs);
     return hipGetLastError();
 }
 

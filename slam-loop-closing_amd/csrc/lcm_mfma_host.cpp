@@ -110,7 +110,7 @@ int mfma_online(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int pitch_rows
     HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
     HIP_TRY(hipEventRecord(q.k1, h->stream));
     h->info_pending = true;
-    h->info.launches = 3; h->info.workgroups = (uint32_t)items.size();
+    h->info.launches = 3; h->info.workgroups = (uint32_t)items.size(); h->info.route = LCM_ROUTE_MATRIX;
     {
         uint64_t dist = 0, bytes = 0;
         for (int b = 0; b < B; ++b) {
@@ -212,7 +212,7 @@ int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int32_t* d_
         }
     }
     h->info_pending = true;
-    h->info.launches = launches; h->info.workgroups = biggest;
+    h->info.launches = launches; h->info.workgroups = biggest; h->info.route = LCM_ROUTE_MATRIX;
     h->info.pairs = offsets[(size_t)n_q]; h->info.distances = dist; h->info.algo_bytes = bytes;
     return LCM_OK;
 }

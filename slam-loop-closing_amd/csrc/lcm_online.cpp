@@ -72,7 +72,7 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
         f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
         e = lcm::launch_finalize(f, (uint32_t)n_elig, h->stream);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
-        h->info.launches = 2; h->info.workgroups = (uint32_t)n_items;
+        h->info.launches = 2; h->info.workgroups = (uint32_t)n_items; h->info.route = LCM_ROUTE_SPLIT;
     } else {
         const int spi = n_elig >= 8192 ? 4 : (n_elig >= 4096 ? 2 : 1);
         const uint32_t n_items = (uint32_t)((n_elig + spi - 1) / spi);
@@ -81,7 +81,7 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
         a.scores = q.d_scores; a.keys = nullptr; a.keys_stride = 0;
         hipError_t e = lcm::launch_score(a, n_items, nq, false, h->variant, h->stream);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-        h->info.launches = 1; h->info.workgroups = n_items;
+        h->info.launches = 1; h->info.workgroups = n_items; h->info.route = LCM_ROUTE_PLAIN;
     }
     HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
     HIP_TRY(hipEventRecord(q.k1, h->stream));
@@ -173,12 +173,12 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
         for (int b = 0; b < B; ++b) f.bat_nq[b] = nq[b];
         e = lcm::launch_finalize(f, pair, h->stream);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
-        h->info.launches = 2;
+        h->info.launches = 2; h->info.route = LCM_ROUTE_SPLIT;
     } else {
         a.scores = q.d_scores; a.keys = nullptr; a.keys_stride = 0;
         hipError_t e = lcm::launch_score(a, wg, max_nq, false, h->variant >= 2 ? 0 : h->variant, h->stream);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-        h->info.launches = 1;
+        h->info.launches = 1; h->info.route = LCM_ROUTE_PLAIN;
     }
     h->info.workgroups = wg;
     HIP_TRY(hipEventRecord(h->ev_stop, h->stream));

@@ -39,7 +39,7 @@ def _run(m, pkg, n, mode, ext=None):
     try:
         got, got2, sums = np.zeros(n, pkg.capi.SCORE_DTYPE), np.zeros(n, pkg.capi.SCORE_DTYPE), np.zeros(n, np.uint32)
         m.all_vs_all(d, n, **kw)
-        launches = m.launch_info().launches if n else 0
+        launches = m.launch_info().route if n else -1
         m.sync(); m.dev_download(d, got)
         m.all_vs_all_argmin(d, n, ds, **kw)
         m.sync(); m.dev_download(d, got2); m.dev_download(ds, sums)
@@ -70,9 +70,9 @@ def test_packed_self_search_is_bit_exact(matcher, oracle, pkg, n_frames, max_des
             np.testing.assert_array_equal(got2, want, err_msg=f"packed={mode} (argmin kernel)")
             np.testing.assert_array_equal(sums, wsums, err_msg=f"packed={mode} (index checksums)")
             if mode == 1:
-                assert launches == 2                     # score + fold: the packed route really ran
+                assert launches == pkg.capi.ROUTE_PACKED      # score + fold kernels: the packed route really ran
             if mode == 0:
-                assert launches == 1
+                assert launches == pkg.capi.ROUTE_PLAIN
         # the fused loop test sits on top of whichever route the plan picked
         matcher.set_tuning(pkg.capi.TUNE_PACKED, 1)
         cands, npairs = matcher.all_vs_all_loops(cap=max(n, 1))
@@ -134,7 +134,8 @@ def test_packed_is_the_automatic_choice_for_orb_sized_frames(matcher, oracle, pk
         assert n >= 8192
         d = matcher.dev_alloc(n * 8)
         matcher.all_vs_all(d, n)
-        assert matcher.launch_info().launches == 2
+        li = matcher.launch_info()
+        assert li.route == pkg.capi.ROUTE_PACKED and li.launches == 2
         got = np.zeros(n, pkg.capi.SCORE_DTYPE)
         matcher.sync(); matcher.dev_download(d, got)
         matcher.dev_free(d)
@@ -157,7 +158,7 @@ def test_packed_is_the_automatic_choice_for_orb_sized_frames(matcher, oracle, pk
         n, _ = matcher.all_vs_all_plan()
         d = matcher.dev_alloc(n * 8)
         matcher.all_vs_all(d, n)
-        assert matcher.launch_info().launches == 1
+        assert matcher.launch_info().route == pkg.capi.ROUTE_PLAIN
         matcher.sync()
         matcher.dev_free(d)
     finally:
