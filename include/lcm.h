@@ -326,8 +326,11 @@ LCM_API int  lcm_merge_shard_scores_device(lcm_handle* h, const void* d_gathered
  *   LCM_TUNE_ITEM_SLOTS   stored frames per work item of the bulk search, 1..64; 0 = automatic
  *   LCM_TUNE_ONLINE_SPLIT query rows per lane of the online split mode: 1, 2, 4; 0 = never split; -1 = automatic
  *   LCM_TUNE_PACKED       bulk search with the query rows of consecutive frames packed into full 2048-row workgroups:
- *                         1 = always, 0 = never, -1 = automatic (when packing saves lane slots) */
-typedef enum lcm_tuning { LCM_TUNE_ITEM_SLOTS = 0, LCM_TUNE_ONLINE_SPLIT = 1, LCM_TUNE_PACKED = 2 } lcm_tuning;
+ *                         1 = always, 0 = never, -1 = automatic (when packing saves lane slots)
+ *   LCM_TUNE_ONLINE_STREAMS 1 (default) = each of the 4 query slots enqueues on its own stream, so consecutive online
+ *                         queries overlap (upload and first workgroups of one under the draining tail of the other);
+ *                         0 = everything on the handle's stream */
+typedef enum lcm_tuning { LCM_TUNE_ITEM_SLOTS = 0, LCM_TUNE_ONLINE_SPLIT = 1, LCM_TUNE_PACKED = 2, LCM_TUNE_ONLINE_STREAMS = 3 } lcm_tuning;
 LCM_API int  lcm_set_tuning(lcm_handle* h, int knob, int value);
 
 /* Device scratch helpers so a host program needs no other allocator (plain hipMalloc/hipFree/hipMemcpy). */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCM_LIB_PATH") or os.path.join(_HERE, "lib", "liblcm_hip.so")
 DESC_BYTES = 32
 KEY_SHIFT = 22
-TUNE_ITEM_SLOTS, TUNE_ONLINE_SPLIT, TUNE_PACKED = 0, 1, 2      # lcm_tuning
+TUNE_ITEM_SLOTS, TUNE_ONLINE_SPLIT, TUNE_PACKED, TUNE_ONLINE_STREAMS = 0, 1, 2, 3      # lcm_tuning
 
 
 class LcmError(RuntimeError):

@@ -40,6 +40,12 @@ int wait_db(lcm_handle* h) {   // make the match stream see every append issued 
     return LCM_OK;
 }
 
+int sync_online_streams(lcm_handle* h) {
+    for (QuerySlot& q : h->qslots)
+        if (q.stream) HIP_TRY(hipStreamSynchronize(q.stream));
+    return LCM_OK;
+}
+
 // Eligible stored slots for a query id are a prefix because ids are strictly increasing by slot.
 int eligible_prefix(const lcm_handle* h, int query_id, int gap) {
     // largest e with frames[e-1].id <= query_id - gap; a frame is never compared with itself (gap >= 1)
@@ -99,6 +105,7 @@ int grow_arena(lcm_handle* h, int need_frames, int need_rows) {
         HIP_TRY(hipMemcpyAsync(ncounts, h->d_counts, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    { int rc = sync_online_streams(h); if (rc) return rc; }      // queries in flight still read the old arena
     if (h->d_rows) HIP_TRY(hipFree(h->d_rows));
     if (h->d_counts) HIP_TRY(hipFree(h->d_counts));
     h->d_rows = nrows; h->d_counts = ncounts;
@@ -201,6 +208,7 @@ void lcm_destroy(lcm_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    for (QuerySlot& q : h->qslots) if (q.stream) (void)hipStreamSynchronize(q.stream);
     (void)hipFree(h->d_rows); (void)hipFree(h->d_counts);
     (void)hipFree(h->d_keys); (void)hipFree(h->plan.d_items); (void)hipFree(h->plan.d_pk_tab);
     (void)hipFree(h->d_bulk_scores); (void)hipFree(h->d_meta); (void)hipFree(h->d_cands);
@@ -212,6 +220,8 @@ void lcm_destroy(lcm_handle* h) {
         if (q.done) (void)hipEventDestroy(q.done);
         if (q.k0) (void)hipEventDestroy(q.k0);
         if (q.k1) (void)hipEventDestroy(q.k1);
+        if (q.fence) (void)hipEventDestroy(q.fence);
+        if (q.stream) (void)hipStreamDestroy(q.stream);
     }
     for (int i = 0; i < STAGE_BUFS; ++i) {
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
@@ -254,7 +264,7 @@ int lcm_sync(lcm_handle* h) {
     int rc = set_device(h); if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->copy_stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return LCM_OK;
+    return sync_online_streams(h);
 }
 
 int lcm_set_kernel_variant(lcm_handle* h, int variant) {
@@ -274,6 +284,9 @@ int lcm_set_tuning(lcm_handle* h, int knob, int value) {
             if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4)
                 return fail(LCM_ERR_INVALID_ARG, "online split must be -1 (automatic), 0 (off), 1, 2 or 4 rows per lane");
             h->tune_online_split = value; return LCM_OK;
+        case LCM_TUNE_ONLINE_STREAMS:
+            if (value != 0 && value != 1) return fail(LCM_ERR_INVALID_ARG, "online streams must be 0 (the handle's stream) or 1 (one per query slot)");
+            h->tune_online_streams = value; return LCM_OK;
         case LCM_TUNE_PACKED:
             if (value < -1 || value > 1) return fail(LCM_ERR_INVALID_ARG, "packed rows must be -1 (automatic), 0 (off) or 1 (on)");
             h->tune_packed = value; h->plan.key = 0; return LCM_OK;
@@ -309,7 +322,7 @@ static int db_append_impl(lcm_handle* h, int frame_id, const uint8_t* desc, int 
     HIP_TRY(hipMemcpyAsync(h->d_counts + slot, h->h_counts + slot, sizeof(int32_t), hipMemcpyHostToDevice, h->copy_stream));
     HIP_TRY(hipEventRecord(h->stage_done[b], h->copy_stream));
     HIP_TRY(hipEventRecord(h->db_ready, h->copy_stream));
-    h->pending_copy = true;
+    h->pending_copy = true; h->db_ready_recorded = true;
     h->frames.push_back({frame_id, n, n_keypoints < 0 ? n : n_keypoints});
     h->plan.key = 0;
     return LCM_OK;

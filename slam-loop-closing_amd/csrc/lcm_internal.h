@@ -69,6 +69,10 @@ struct FrameMeta {
 
 constexpr int QUERY_SLOTS = 4;    // online queries that may be in flight at once (lcm_query_submit / _collect)
 constexpr int STAGE_BUFS = 2;
+// A micro-batch of fewer pairs than this is scored in split mode (1024-row chunks at the top of the range): with the
+// slots on separate streams, finer workgroups let the next launch fill in behind the draining one.  Measured with
+// bench.py --mode stream (8 frames per batch): 2500 frames 2.81e12 (limit 12288) -> 2.86e12.
+constexpr size_t ONLINE_SPLIT_MAX_PAIRS = 65536;
 
 struct QuerySlot {                // everything one in-flight online query owns
     bool busy = false;
@@ -85,6 +89,12 @@ struct QuerySlot {                // everything one in-flight online query owns
     uint8_t* d_meta = nullptr;    size_t d_meta_bytes = 0;
     hipEvent_t done = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;      // around this query's kernel(s): summed into the handle's online stats
+    // The slot's own stream: consecutive online queries run on different streams, so the upload and the first
+    // workgroups of query k + 1 overlap the draining tail of query k's launch (a launch of a few thousand workgroups
+    // leaves the chip partly idle while its last ones finish).  `fence` orders the slot stream after everything
+    // enqueued on the handle's stream before the submit.
+    hipStream_t stream = nullptr;
+    hipEvent_t fence = nullptr;
     uint64_t acc_pairs = 0, acc_distances = 0, acc_bytes = 0;
     uint32_t acc_launches = 0, acc_queries = 0;
 };
@@ -128,6 +138,7 @@ struct lcm_handle {
     int variant = 0;
     int tune_item_slots = 0;           // 0 = automatic (pick_chunk)
     int tune_online_split = -1;        // -1 = automatic (enqueue_query)
+    int tune_online_streams = 1;       // 1 = every query slot runs on its own stream, 0 = all on the handle's stream
     int tune_packed = -1;              // -1 = automatic (bulk plan: when it saves lane slots), 0 = never, 1 = always
 
     // database arena
@@ -137,6 +148,7 @@ struct lcm_handle {
     int stride_rows = 0;               // rows per frame slot (multiple of ROW_PAD)
     std::vector<FrameMeta> frames;
     bool pending_copy = false;
+    bool db_ready_recorded = false;    // db_ready has been recorded at least once (slot streams wait on it)
 
     // pinned staging ring for streaming appends
     uint8_t* h_stage[lcm::STAGE_BUFS] = {nullptr, nullptr};
@@ -202,6 +214,7 @@ namespace lcm {
 // ---- lcm_api.cpp
 int set_device(const lcm_handle* h);
 int wait_db(lcm_handle* h);            // make the match stream see every append issued so far
+int sync_online_streams(lcm_handle* h);   // host-wait for every query slot's own stream
 int eligible_prefix(const lcm_handle* h, int query_id, int gap);   // eligible stored slots are a prefix: its length
 int pick_chunk(const lcm_handle* h, size_t total_pairs);
 int launch_and_time(lcm_handle* h, const ScoreArgs& a, uint32_t n_items, int max_q_rows, bool write_keys);
@@ -231,6 +244,7 @@ using lcm::mfma_online;
 using lcm::pick_chunk;
 using lcm::QUERY_SLOTS;
 using lcm::set_device;
+using lcm::sync_online_streams;
 using lcm::STAGE_BUFS;
 using lcm::wait_db;
 }  // namespace

@@ -569,12 +569,12 @@ static hipError_t launch_rowlane(const ScoreArgs& a, uint32_t n_items, bool writ
 // lane -> 2, 4 or 8 workgroups per pair), every chunk writes its rows' best distances, and this kernel — one
 // workgroup per pair — folds them into the usual score record (min-of-mins, ratio filter, count).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize_pairs(FinalizeArgs a) {
-    __shared__ uint32_t red_min, red_sum;
-    const int tid = threadIdx.x;
-    const uint32_t pair = blockIdx.x;
-    if (tid == 0) { red_min = 0xFFFFFFFFu; red_sum = 0u; }
-    __syncthreads();
+// One WAVE per pair: the pair's <= 2048 per-row distances are read once (8 coalesced 16-byte loads per lane) and stay
+// in registers for both passes; wave reductions are shuffles.
+__global__ __launch_bounds__(256) void k_finalize_pairs(FinalizeArgs a, uint32_t n_pairs) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t pair = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (pair >= n_pairs) return;                                // whole wave: no barrier follows
     int nq = a.nq;
     uint32_t slot = a.slot_begin + pair;
     if (a.n_batch) {
@@ -583,22 +583,34 @@ __global__ __launch_bounds__(256) void k_finalize_pairs(FinalizeArgs a) {
         nq = a.bat_nq[b];
         slot = pair - a.bat_pair[b];
     }
-    const uint32_t* d = a.dist + (size_t)pair * a.padded_rows;
+    const uint4* d = reinterpret_cast<const uint4*>(a.dist + (size_t)pair * a.padded_rows);     // padded_rows % 256 == 0
+    uint32_t v[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r0 = (i * 64 + lane) * 4;                     // rows r0 .. r0 + 3; rows >= nq were never written: masked
+        uint4 x = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (r0 < nq) x = d[i * 64 + lane];
+        v[4 * i + 0] = x.x;
+        v[4 * i + 1] = r0 + 1 < nq ? x.y : 0xFFFFFFFFu;
+        v[4 * i + 2] = r0 + 2 < nq ? x.z : 0xFFFFFFFFu;
+        v[4 * i + 3] = r0 + 3 < nq ? x.w : 0xFFFFFFFFu;
+    }
     uint32_t dmin = 0xFFFFFFFFu;
-    for (int r = tid; r < nq; r += 256) dmin = min(dmin, d[r]);
-    atomicMin(&red_min, dmin);
-    __syncthreads();
-    dmin = red_min;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) dmin = min(dmin, v[k]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
     const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
     uint32_t cnt = 0;
-    for (int r = tid; r < nq; r += 256) cnt += d[r] <= thr ? 1u : 0u;
-    atomicAdd(&red_sum, cnt);
-    __syncthreads();
-    if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) cnt += (v[k] != 0xFFFFFFFFu && v[k] <= thr) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+    if (lane == 0) {
         const int nt = a.db_counts[slot];
-        const bool empty = (nq <= 0) || (nt <= 0);
+        const bool empty = (nq <= 0) || (nt <= 0) || dmin == 0xFFFFFFFFu;
         uint2 rec;
-        rec.x = empty ? 0u : red_sum;
+        rec.x = empty ? 0u : cnt;
         rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
         reinterpret_cast<uint2*>(a.scores)[pair] = rec;
     }
@@ -623,7 +635,7 @@ hipError_t launch_fold_pair_keys(const FoldArgs& a, uint32_t max_nq, hipStream_t
 
 hipError_t launch_finalize(const FinalizeArgs& a, uint32_t n_pairs, hipStream_t st) {
     if (n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_finalize_pairs, dim3(n_pairs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_finalize_pairs, dim3((n_pairs + 3) / 4), dim3(256), 0, st, a, n_pairs);
     return hipGetLastError();
 }
 

@@ -15,10 +15,10 @@ static void account_prefix(lcm_handle* h, int nq, int n_elig) {
 // slots [0, n_elig), and the download of the n_elig score records into the slot's pinned buffer.  Work items are
 // implicit (derived from blockIdx), so nothing but the query itself crosses PCIe.  Short databases use the split
 // mode (lcm_kernels.hip): 2 / 4 / 8 workgroups per pair + the on-device fold.
-static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int nq, int n_elig) {
+static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int nq, int n_elig, hipStream_t S) {
     q.n_elig = n_elig; q.nq = nq; q.n_batch = 0;
     q.acc_pairs = q.acc_distances = q.acc_bytes = 0; q.acc_launches = 0; q.acc_queries = 1;
-    if (n_elig <= 0) { HIP_TRY(hipEventRecord(q.done, h->stream)); return LCM_OK; }
+    if (n_elig <= 0) { HIP_TRY(hipEventRecord(q.done, S)); return LCM_OK; }
     int rc = wait_db(h); if (rc) return rc;
     if (h->params.cross_check) {
         // both directions + the on-device mutual test; the caller has padded the query rows for the train role
@@ -54,8 +54,8 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
     a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
     a.imp_nq = nq; a.imp_total = (uint32_t)n_elig;
-    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-    HIP_TRY(hipEventRecord(q.k0, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_start, S));
+    HIP_TRY(hipEventRecord(q.k0, S));
     if (qpt == 1 || qpt == 2 || qpt == 4) {
         const int chunk_rows = 256 * qpt;
         const int n_chunks = (nq + chunk_rows - 1) / chunk_rows;
@@ -64,13 +64,13 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
         a.q_stride_words = (uint32_t)chunk_rows * LCM_DESC_WORDS;
         a.imp_chunks = (uint32_t)n_chunks; a.imp_chunk_rows = (uint32_t)chunk_rows; a.imp_spi = 1;
         a.scores = nullptr /* split mode writes no per-chunk records */; a.keys = q.d_dist; a.keys_stride = (uint32_t)chunk_rows;
-        hipError_t e = lcm::launch_score_split(a, (uint32_t)n_items, qpt, h->stream);
+        hipError_t e = lcm::launch_score_split(a, (uint32_t)n_items, qpt, S);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         lcm::FinalizeArgs f{};
         f.dist = q.d_dist; f.padded_rows = (uint32_t)(n_chunks * chunk_rows); f.nq = nq;
         f.db_counts = h->d_counts; f.slot_begin = 0; f.scores = q.d_scores;
         f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
-        e = lcm::launch_finalize(f, (uint32_t)n_elig, h->stream);
+        e = lcm::launch_finalize(f, (uint32_t)n_elig, S);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
         h->info.launches = 2; h->info.workgroups = (uint32_t)n_items; h->info.route = LCM_ROUTE_SPLIT;
     } else {
@@ -79,18 +79,18 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
         a.q_stride_words = 0;
         a.imp_chunks = 1; a.imp_chunk_rows = (uint32_t)std::max(nq, 1); a.imp_spi = (uint32_t)spi;
         a.scores = q.d_scores; a.keys = nullptr; a.keys_stride = 0;
-        hipError_t e = lcm::launch_score(a, n_items, nq, false, h->variant, h->stream);
+        hipError_t e = lcm::launch_score(a, n_items, nq, false, h->variant, S);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         h->info.launches = 1; h->info.workgroups = n_items; h->info.route = LCM_ROUTE_PLAIN;
     }
-    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
-    HIP_TRY(hipEventRecord(q.k1, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_stop, S));
+    HIP_TRY(hipEventRecord(q.k1, S));
     h->info_pending = true;
     account_prefix(h, nq, n_elig);
     q.acc_pairs = h->info.pairs; q.acc_distances = h->info.distances; q.acc_bytes = h->info.algo_bytes;
     q.acc_launches = h->info.launches; q.acc_queries = 1;
-    HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(q.done, h->stream));
+    HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * (size_t)n_elig, hipMemcpyDeviceToHost, S));
+    HIP_TRY(hipEventRecord(q.done, S));
     return LCM_OK;
 }
 
@@ -98,13 +98,13 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
 // against stored slots [0, elig[b]) each, ONE score launch (+ one finalize launch in split mode), one download.
 // A launch of B x n_elig pairs fills the chip where a single query's few hundred pairs leave its tail idle, and the
 // host pays one submit / collect round trip per B frames.
-static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int rows_per_query, int B, const int* nq, const int* elig) {
+static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int rows_per_query, int B, const int* nq, const int* elig, hipStream_t S) {
     size_t total = 0;
     int max_nq = 0;
     for (int b = 0; b < B; ++b) { total += (size_t)elig[b]; max_nq = std::max(max_nq, nq[b]); q.bat_elig[b] = elig[b]; }
     q.n_batch = B; q.n_elig = (int)total; q.nq = max_nq;
     q.acc_pairs = q.acc_distances = q.acc_bytes = 0; q.acc_launches = 0; q.acc_queries = (uint32_t)B;
-    if (total == 0) { HIP_TRY(hipEventRecord(q.done, h->stream)); return LCM_OK; }
+    if (total == 0) { HIP_TRY(hipEventRecord(q.done, S)); return LCM_OK; }
     if (total > 0x7FFFFFFFull) return fail(LCM_ERR_CAPACITY, "more than 2^31 pairs in one batch");
     int rc = wait_db(h); if (rc) return rc;
     if (h->params.cross_check) {
@@ -126,7 +126,7 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
         if (h->tune_online_split >= 0) qpt = h->tune_online_split;
         else if (total < 1536) qpt = 1;          // same rule as a single query, on the batch's total pair count
         else if (total < 6144) qpt = 2;
-        else if (total < 12288) qpt = 4;
+        else if (total < lcm::ONLINE_SPLIT_MAX_PAIRS) qpt = 4;
     }
     rc = ensure_dev(q.d_scores, q.d_scores_n, total); if (rc) return rc;
     rc = ensure_pinned(q.h_scores, q.h_scores_n, total); if (rc) return rc;
@@ -157,12 +157,12 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
     // chunk index of query b's chunk c is b * imp_chunks + c in the kernel; with a pitch of chunk_slots chunks per query
     // that only holds when imp_chunks == chunk_slots: the staging copy below packs the queries at that pitch
     if ((uint32_t)n_chunks != chunk_slots) return fail(LCM_ERR_HIP, "internal: batch pitch %u != %d chunks", chunk_slots, n_chunks);
-    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-    HIP_TRY(hipEventRecord(q.k0, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_start, S));
+    HIP_TRY(hipEventRecord(q.k0, S));
     if (split) {
         rc = ensure_dev(q.d_dist, q.d_dist_n, total * (size_t)n_chunks * chunk_rows); if (rc) return rc;
         a.scores = nullptr; a.keys = q.d_dist; a.keys_stride = (uint32_t)chunk_rows;
-        hipError_t e = lcm::launch_score_split(a, wg, qpt, h->stream);
+        hipError_t e = lcm::launch_score_split(a, wg, qpt, S);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         lcm::FinalizeArgs f{};
         f.dist = q.d_dist; f.padded_rows = (uint32_t)(n_chunks * chunk_rows); f.nq = 0;
@@ -171,18 +171,18 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
         f.n_batch = (uint32_t)B;
         for (int b = 0; b <= B; ++b) f.bat_pair[b] = a.bat_pair[b];
         for (int b = 0; b < B; ++b) f.bat_nq[b] = nq[b];
-        e = lcm::launch_finalize(f, pair, h->stream);
+        e = lcm::launch_finalize(f, pair, S);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "finalize launch failed: %s", hipGetErrorString(e));
         h->info.launches = 2; h->info.route = LCM_ROUTE_SPLIT;
     } else {
         a.scores = q.d_scores; a.keys = nullptr; a.keys_stride = 0;
-        hipError_t e = lcm::launch_score(a, wg, max_nq, false, h->variant >= 2 ? 0 : h->variant, h->stream);
+        hipError_t e = lcm::launch_score(a, wg, max_nq, false, h->variant >= 2 ? 0 : h->variant, S);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         h->info.launches = 1; h->info.route = LCM_ROUTE_PLAIN;
     }
     h->info.workgroups = wg;
-    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
-    HIP_TRY(hipEventRecord(q.k1, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_stop, S));
+    HIP_TRY(hipEventRecord(q.k1, S));
     h->info_pending = true;
     {
         uint64_t dist = 0, bytes = 0, prows = 0;
@@ -198,8 +198,8 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
         h->info.pairs = total; h->info.distances = dist; h->info.algo_bytes = bytes;
         q.acc_pairs = total; q.acc_distances = dist; q.acc_bytes = bytes; q.acc_launches = h->info.launches;
     }
-    HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * total, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(q.done, h->stream));
+    HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * total, hipMemcpyDeviceToHost, S));
+    HIP_TRY(hipEventRecord(q.done, S));
     return LCM_OK;
 }
 
@@ -226,10 +226,25 @@ static int acquire_query_slot(lcm_handle* h, int* ticket) {
             if (!h->qslots[i].done) HIP_TRY(hipEventCreateWithFlags(&h->qslots[i].done, hipEventDisableTiming));
             if (!h->qslots[i].k0) HIP_TRY(hipEventCreate(&h->qslots[i].k0));
             if (!h->qslots[i].k1) HIP_TRY(hipEventCreate(&h->qslots[i].k1));
+            if (!h->qslots[i].fence) HIP_TRY(hipEventCreateWithFlags(&h->qslots[i].fence, hipEventDisableTiming));
+            if (!h->qslots[i].stream) HIP_TRY(hipStreamCreateWithFlags(&h->qslots[i].stream, hipStreamNonBlocking));
             *ticket = i;
             return LCM_OK;
         }
     return fail(LCM_ERR_CAPACITY, "%d queries already in flight: collect one first", QUERY_SLOTS);
+}
+
+// The stream an online query runs on: the slot's own (QuerySlot::stream) for the vector-ALU kernels, ordered after
+// everything already enqueued on the handle's stream and after every append issued so far; the handle's stream for
+// the routes that use handle-wide scratch (cross_check, matrix-core variants) or when LCM_TUNE_ONLINE_STREAMS is 0.
+static int pick_stream(lcm_handle* h, QuerySlot& q, hipStream_t* S) {
+    *S = h->stream;
+    if (h->params.cross_check || h->variant >= 4 || !h->tune_online_streams) return LCM_OK;
+    HIP_TRY(hipEventRecord(q.fence, h->stream));
+    HIP_TRY(hipStreamWaitEvent(q.stream, q.fence, 0));
+    if (h->db_ready_recorded) HIP_TRY(hipStreamWaitEvent(q.stream, h->db_ready, 0));
+    *S = q.stream;
+    return LCM_OK;
 }
 
 static int query_submit_impl(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, int* ticket) {
@@ -248,12 +263,14 @@ static int query_submit_impl(lcm_handle* h, const uint8_t* query, int nq, int qu
     const size_t bytes = (size_t)std::max(rows_up, 1) * LCM_DESC_BYTES;
     rc = ensure_pinned(q.h_query, q.h_query_bytes, bytes); if (rc) return rc;
     rc = ensure_dev(q.d_query, q.d_query_bytes, bytes, ARENA_SLACK); if (rc) return rc;
+    hipStream_t S;
+    rc = pick_stream(h, q, &S); if (rc) return rc;
     if (nq > 0 && n_elig > 0) {
         memcpy(q.h_query, query, (size_t)nq * LCM_DESC_BYTES);       // the caller's buffer is free when we return
         for (int r = nq; r < rows_up; ++r) memcpy(q.h_query + (size_t)r * LCM_DESC_BYTES, query + (size_t)(nq - 1) * LCM_DESC_BYTES, LCM_DESC_BYTES);
-        HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, (size_t)rows_up * LCM_DESC_BYTES, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, (size_t)rows_up * LCM_DESC_BYTES, hipMemcpyHostToDevice, S));
     }
-    rc = enqueue_query(h, q, (const uint32_t*)q.d_query, nq, n_elig); if (rc) return rc;
+    rc = enqueue_query(h, q, (const uint32_t*)q.d_query, nq, n_elig, S); if (rc) return rc;
     q.busy = true;
     q.db_generation = h->db_generation;
     *ticket = t;
@@ -314,7 +331,7 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
             if (h->tune_online_split >= 0) qpt = h->tune_online_split;
             else if (total < 1536) qpt = 1;
             else if (total < 6144) qpt = 2;
-            else if (total < 12288) qpt = 4;
+            else if (total < lcm::ONLINE_SPLIT_MAX_PAIRS) qpt = 4;
         }
         if (qpt == 1 || qpt == 2 || qpt == 4) pitch = round_up(max_nq, 256 * qpt);
     }
@@ -322,6 +339,8 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
     const size_t bytes = (size_t)pitch * (size_t)n_queries * LCM_DESC_BYTES;
     rc = ensure_pinned(q.h_query, q.h_query_bytes, bytes); if (rc) return rc;
     rc = ensure_dev(q.d_query, q.d_query_bytes, bytes, ARENA_SLACK); if (rc) return rc;
+    hipStream_t S;
+    rc = pick_stream(h, q, &S); if (rc) return rc;
     if (total > 0) {
         for (int b = 0; b < n_queries; ++b)          // the callers' buffers are free when we return
             if (nq[b] > 0) {
@@ -330,9 +349,9 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
                 if (h->params.cross_check)
                     for (int r = nq[b]; r < padded_rows(nq[b]) + ROW_PAD; ++r) memcpy(dst + (size_t)r * LCM_DESC_BYTES, queries[b] + (size_t)(nq[b] - 1) * LCM_DESC_BYTES, LCM_DESC_BYTES);
             }
-        HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, bytes, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, bytes, hipMemcpyHostToDevice, S));
     }
-    rc = enqueue_batch(h, q, (const uint32_t*)q.d_query, pitch, n_queries, nq, elig); if (rc) return rc;
+    rc = enqueue_batch(h, q, (const uint32_t*)q.d_query, pitch, n_queries, nq, elig, S); if (rc) return rc;
     q.busy = true;
     q.db_generation = h->db_generation;
     *ticket = t;
@@ -395,8 +414,10 @@ static int detect_loops_impl(lcm_handle* h, int current_frame_id, const uint8_t*
         rc = acquire_query_slot(h, &t); if (rc) return rc;
         QuerySlot& q = h->qslots[t];
         q.query_id = current_frame_id;
+        hipStream_t S;
+        rc = pick_stream(h, q, &S); if (rc) return rc;
         rc = enqueue_query(h, q, (const uint32_t*)(h->d_rows + (size_t)slot * h->stride_rows * LCM_DESC_BYTES), nq,
-                           eligible_prefix(h, current_frame_id, h->params.min_gap));
+                           eligible_prefix(h, current_frame_id, h->params.min_gap), S);
         if (rc) return rc;
         q.busy = true;
         q.db_generation = h->db_generation;

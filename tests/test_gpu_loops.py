@@ -588,3 +588,56 @@ def test_matrix_core_variant_is_bit_exact(matcher, oracle, pkg, n_frames, max_de
         matcher.set_kernel_variant(0)
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+@pytest.mark.parametrize("own_streams", [1, 0])
+def test_four_tickets_in_flight_with_appends_between_them(matcher, oracle, pkg, own_streams):
+    """LCM_TUNE_ONLINE_STREAMS: every query slot enqueues on its own stream (default) so consecutive online launches
+    overlap.  Four tickets in flight — single queries and micro-batches — with host appends AND a device append between
+    the submits (each query must see exactly the frames stored before it), collected out of order: records == oracle,
+    and the same with everything on the handle's stream."""
+    fs = pkg.synth.make_frames(60, 1400, seed=77, ragged=True, dup_frac=0.3)
+    gap = 3
+    matcher.set_params(min_gap=gap)
+    matcher.set_tuning(pkg.capi.TUNE_ONLINE_STREAMS, own_streams)
+    p = oracle.default_params(min_gap=gap)
+    d_frame = matcher.dev_alloc(fs.stride_rows * 32)
+    try:
+        matcher.clear()
+        matcher.reserve(fs.n_frames, fs.stride_rows)
+        for f in range(40):
+            matcher.append(int(fs.ids[f]), fs.frame(f))
+        want, woffs = fast_all_vs_all(oracle, fs, p)
+
+        def rows_of(f):
+            return want[int(woffs[f]): int(woffs[f + 1])]
+
+        tickets = []
+        tickets.append(("one", [40], matcher.query_submit(fs.frame(40), int(fs.ids[40]))))
+        matcher.append(int(fs.ids[40]), fs.frame(40))                             # host append: copy stream
+        tickets.append(("batch", [41, 42], matcher.query_submit_batch([fs.frame(41), fs.frame(42)], [int(fs.ids[41]), int(fs.ids[42])])))
+        matcher.dev_upload(d_frame, np.ascontiguousarray(fs.rows[41]))
+        matcher.append_device(int(fs.ids[41]), d_frame, int(fs.counts[41]))       # device append: the handle's stream
+        matcher.append(int(fs.ids[42]), fs.frame(42))
+        tickets.append(("one", [45], matcher.query_submit(fs.frame(45), int(fs.ids[45]))))    # sees 41 and 42 (gap 3)
+        tickets.append(("batch", [46, 47, 48], matcher.query_submit_batch([fs.frame(f) for f in (46, 47, 48)], [int(fs.ids[f]) for f in (46, 47, 48)])))
+        with pytest.raises(pkg.capi.LcmError):                                    # a fifth would need a fifth slot
+            matcher.query_submit(fs.frame(49), int(fs.ids[49]))
+        for kind, frames, t in reversed(tickets):
+            if kind == "one":
+                sc, _ = matcher.query_collect(t)
+                np.testing.assert_array_equal(sc, rows_of(frames[0])[: len(sc)])
+                assert len(sc) == min(len(rows_of(frames[0])), 43 if frames[0] == 45 else 40)
+            else:
+                sc, boffs = matcher.query_collect_batch(t)
+                for j, f in enumerate(frames):
+                    got = sc[int(boffs[j]): int(boffs[j + 1])]
+                    np.testing.assert_array_equal(got, rows_of(f)[: len(got)])
+                    assert len(got) > 0
+        # frame 45 was eligible for 41 and 42 only if they had landed before its launch: ids 41, 42 <= 45 - 3
+        matcher.sync()
+    finally:
+        matcher.dev_free(d_frame)
+        matcher.set_tuning(pkg.capi.TUNE_ONLINE_STREAMS, 1)
+        matcher.set_params(min_gap=30)
+        matcher.clear()
