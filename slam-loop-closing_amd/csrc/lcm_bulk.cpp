@@ -2,6 +2,110 @@
 // Part of liblcm_hip.so's host side (C ABI in include/lcm.h); shared state and helpers: lcm_internal.h.
 #include "lcm_internal.h"
 
+namespace {
+
+// The packed form of a bulk search (lcm_kernels.h, ScoreArgs::pk_*).  Per chunk of <= PK_CHUNK_PAIRS pairs (8 KB of
+// per-row scratch each) the query frames that have work are laid end to end in order of descending eligibility and cut
+// into 2048-row columns; a column is scored against slots [0, eligibility of its first frame) in runs of `chunk` slots.
+struct PackedPlan {
+    std::vector<uint32_t> tab;                  // [pair offsets (n_q + 1) | row counts (n_q) | per chunk: vstart, qframe, elig, pairs]
+    std::vector<lcm::WorkItem> items;           // (column, slot run) items, chunk by chunk; out_offset = the column's first position
+    std::vector<Plan::PackedChunk> chunks;
+    size_t max_pairs = 0;                       // largest chunk
+    uint64_t lane_slots = 0;                    // sum over columns of 2048 x slots scored: what the launch occupies
+};
+
+int build_packed_plan(const std::vector<size_t>& offsets, const std::vector<int32_t>& qn, const uint32_t* q_frame_of, int chunk,
+                      PackedPlan& pk) {
+    constexpr size_t PK_CHUNK_PAIRS = 1u << 20;
+    constexpr uint32_t COL = (uint32_t)lcm::MAX_FUSED_QUERY_ROWS;
+    const int n_q = (int)qn.size();
+    auto elig_of = [&](int c) { return (uint32_t)(offsets[(size_t)c + 1] - offsets[(size_t)c]); };
+    pk.tab.resize((size_t)n_q * 2 + 1);
+    for (int c = 0; c <= n_q; ++c) pk.tab[(size_t)c] = (uint32_t)offsets[(size_t)c];
+    for (int c = 0; c < n_q; ++c) pk.tab[(size_t)n_q + 1 + (size_t)c] = (uint32_t)qn[(size_t)c];
+    std::vector<int> pos;
+    int c0 = 0;
+    while (c0 < n_q) {
+        int c1 = c0;
+        size_t pairs = 0;
+        while (c1 < n_q && (pairs == 0 || pairs + elig_of(c1) <= PK_CHUNK_PAIRS)) { pairs += elig_of(c1); ++c1; }
+        if (pairs > 0) {
+            pos.clear();
+            for (int c = c0; c < c1; ++c) if (elig_of(c) > 0 && qn[(size_t)c] > 0) pos.push_back(c);
+            std::stable_sort(pos.begin(), pos.end(), [&](int x, int y) { return elig_of(x) > elig_of(y); });
+            Plan::PackedChunk ch{};
+            ch.item0 = (uint32_t)pk.items.size(); ch.tab0 = (uint32_t)pk.tab.size(); ch.n_pos = (uint32_t)pos.size();
+            ch.pair_base = (uint32_t)offsets[(size_t)c0]; ch.n_pairs = (uint32_t)pairs;
+            const size_t np = pos.size();
+            pk.tab.resize(pk.tab.size() + 4 * np + 1);
+            uint32_t* vstart = pk.tab.data() + ch.tab0;
+            uint32_t* qframe = vstart + np + 1;
+            uint32_t* eligp = qframe + np;
+            uint32_t* pairsp = eligp + np;
+            uint64_t v = 0;
+            for (size_t k = 0; k < np; ++k) {
+                const int c = pos[k];
+                vstart[k] = (uint32_t)v; v += (uint64_t)qn[(size_t)c];
+                qframe[k] = q_frame_of ? q_frame_of[c] : (uint32_t)c;
+                eligp[k] = elig_of(c);
+                pairsp[k] = (uint32_t)(offsets[(size_t)c] - offsets[(size_t)c0]);
+            }
+            if (v > 0xFFFFFFFFull) return fail(LCM_ERR_CAPACITY, "more than 2^32 query rows in one chunk");
+            vstart[np] = (uint32_t)v;
+            size_t k = 0;
+            for (uint64_t w = 0; w * COL < v; ++w) {
+                while (vstart[k + 1] <= w * COL) ++k;          // position holding the column's first row
+                const uint32_t me = eligp[k];                  // the largest eligibility in the column (descending order)
+                pk.lane_slots += (uint64_t)COL * me;
+                for (uint32_t b = 0; b < me; b += (uint32_t)chunk)
+                    pk.items.push_back({(uint32_t)w, b, std::min((uint32_t)chunk, me - b), (uint32_t)k});
+            }
+            ch.n_items = (uint32_t)pk.items.size() - ch.item0;
+            pk.chunks.push_back(ch);
+            pk.max_pairs = std::max(pk.max_pairs, pairs);
+        }
+        c0 = c1;
+    }
+    return LCM_OK;
+}
+
+// Packed route: score kernel (per-row best distance / key of every eligible pair) + fold kernel, chunk by chunk on one
+// stream: the fold of chunk k is done with the scratch before the scores of chunk k + 1 are written.
+int launch_packed(lcm_handle* h, const Plan& P, lcm::ScoreArgs a, bool argmin, void* d_scores, uint32_t* d_idx_sums) {
+    int rc = ensure_dev(h->d_mdist, h->d_mdist_n, P.pk_max_pairs * (size_t)lcm::MAX_FUSED_QUERY_ROWS); if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    uint32_t launches = 0, biggest = 0;
+    for (const Plan::PackedChunk& ch : P.pk_chunks) {
+        a.items = P.d_items + ch.item0;
+        a.pk_vstart = P.d_pk_tab + ch.tab0;
+        a.pk_qframe = a.pk_vstart + ch.n_pos + 1;
+        a.pk_elig = a.pk_qframe + ch.n_pos;
+        a.pk_pairs = a.pk_elig + ch.n_pos;
+        a.pk_dist = h->d_mdist; a.pk_n = ch.n_pos;
+        hipError_t e = lcm::launch_score_packed(a, ch.n_items, argmin, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        lcm::FinalizeBulkArgs f{};
+        f.key_shift = argmin ? lcm::KEY_SHIFT : 0; f.idx_sums = d_idx_sums;
+        f.dist = h->d_mdist; f.offsets = P.d_pk_tab; f.nq = reinterpret_cast<const int32_t*>(P.d_pk_tab + P.pk_n_q + 1);
+        f.db_counts = h->d_counts; f.scores = d_scores; f.n_q = P.pk_n_q; f.pair_base = ch.pair_base;
+        f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
+        const bool last = (&ch == &P.pk_chunks.back());      // the last chunk's fold is timed by itself (aux_kernel_ms)
+        if (last) HIP_TRY(hipEventRecord(h->ev_aux_start, h->stream));
+        e = lcm::launch_finalize_bulk(f, ch.n_pairs, h->stream);
+        if (e != hipSuccess) return fail(LCM_ERR_HIP, "fold kernel launch failed: %s", hipGetErrorString(e));
+        if (last) { HIP_TRY(hipEventRecord(h->ev_aux_stop, h->stream)); h->aux_pending = true; }
+        launches += 2; biggest = std::max(biggest, ch.n_items);
+    }
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    h->info_pending = true;
+    h->info.launches = launches; h->info.workgroups = biggest; h->info.route = LCM_ROUTE_PACKED;
+    h->info.pairs = P.n_pairs; h->info.distances = P.distances; h->info.algo_bytes = P.algo_bytes;
+    return LCM_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 /* ---- bulk all-vs-all --------------------------------------------------------------------------------- */
@@ -81,75 +185,23 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
         }
         if (P.max_q_rows > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "query frames may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
 
-        // ---- packed form: per chunk of <= PK_CHUNK_PAIRS pairs (8 KB of per-row scratch each), the query frames that
-        // have work are laid end to end in order of descending eligibility and cut into 2048-row columns; a column is
-        // scored against slots [0, eligibility of its first frame) in runs of `chunk` slots.
-        std::vector<uint32_t> tab;
-        std::vector<lcm::WorkItem> pk_items;
-        std::vector<Plan::PackedChunk> pk_chunks;
-        size_t pk_max_pairs = 0;
+        // ---- packed form (ScoreArgs::pk_*): built beside the accounting, adopted when it saves lane slots
+        PackedPlan pk;
         if (pack_ok && total > 0) {
-            constexpr size_t PK_CHUNK_PAIRS = 1u << 20;
-            constexpr uint32_t COL = (uint32_t)lcm::MAX_FUSED_QUERY_ROWS;
-            uint64_t lanes_packed = 0;
-            tab.resize((size_t)n_q_frames * 2 + 1);
-            for (int c = 0; c <= n_q_frames; ++c) tab[(size_t)c] = (uint32_t)P.offsets[(size_t)c];
-            for (int c = 0; c < n_q_frames; ++c) tab[(size_t)n_q_frames + 1 + (size_t)c] = (uint32_t)qn[(size_t)c];
-            std::vector<int> pos;
-            int c0 = 0;
-            while (c0 < n_q_frames) {
-                int c1 = c0;
-                size_t pairs = 0;
-                while (c1 < n_q_frames && (pairs == 0 || pairs + elig_of(c1) <= PK_CHUNK_PAIRS)) { pairs += elig_of(c1); ++c1; }
-                if (pairs > 0) {
-                    pos.clear();
-                    for (int c = c0; c < c1; ++c) if (elig_of(c) > 0 && qn[(size_t)c] > 0) pos.push_back(c);
-                    std::stable_sort(pos.begin(), pos.end(), [&](int x, int y) { return elig_of(x) > elig_of(y); });
-                    Plan::PackedChunk ch{};
-                    ch.item0 = (uint32_t)pk_items.size(); ch.tab0 = (uint32_t)tab.size(); ch.n_pos = (uint32_t)pos.size();
-                    ch.pair_base = (uint32_t)P.offsets[(size_t)c0]; ch.n_pairs = (uint32_t)pairs;
-                    const size_t np = pos.size();
-                    tab.resize(tab.size() + 4 * np + 1);
-                    uint32_t* vstart = tab.data() + ch.tab0;
-                    uint32_t* qframe = vstart + np + 1;
-                    uint32_t* eligp = qframe + np;
-                    uint32_t* pairsp = eligp + np;
-                    uint64_t v = 0;
-                    for (size_t k = 0; k < np; ++k) {
-                        const int c = pos[k];
-                        vstart[k] = (uint32_t)v; v += (uint64_t)qn[(size_t)c];
-                        qframe[k] = q_frame_of ? q_frame_of[c] : (uint32_t)c;
-                        eligp[k] = elig_of(c);
-                        pairsp[k] = (uint32_t)(P.offsets[(size_t)c] - P.offsets[(size_t)c0]);
-                    }
-                    if (v > 0xFFFFFFFFull) return fail(LCM_ERR_CAPACITY, "more than 2^32 query rows in one chunk");
-                    vstart[np] = (uint32_t)v;
-                    size_t k = 0;
-                    for (uint64_t w = 0; w * COL < v; ++w) {
-                        while (vstart[k + 1] <= w * COL) ++k;          // position holding the column's first row
-                        const uint32_t me = eligp[k];
-                        lanes_packed += (uint64_t)COL * me;
-                        for (uint32_t b = 0; b < me; b += (uint32_t)chunk)
-                            pk_items.push_back({(uint32_t)w, b, std::min((uint32_t)chunk, me - b), (uint32_t)k});
-                    }
-                    ch.n_items = (uint32_t)pk_items.size() - ch.item0;
-                    pk_chunks.push_back(ch);
-                    pk_max_pairs = std::max(pk_max_pairs, pairs);
-                }
-                c0 = c1;
-            }
+            rc = build_packed_plan(P.offsets, qn, q_frame_of, chunk, pk); if (rc) return rc;
             const uint64_t shape_rows = P.max_q_rows <= 512 ? 512 : P.max_q_rows <= 1024 ? 1024 : P.max_q_rows <= 1536 ? 1536 : 2048;
             const uint64_t lanes_plain = (uint64_t)total * shape_rows;
             // automatic: worth it when it saves >= 1 % of the lane slots of a search big enough to be throughput-bound
-            P.packed = h->tune_packed == 1 || (total >= 8192 && lanes_packed * 100 <= lanes_plain * 99);
+            P.packed = h->tune_packed == 1 || (total >= 8192 && pk.lane_slots * 100 <= lanes_plain * 99);
         }
         if (P.packed) {
-            P.items.swap(pk_items);
-            P.pk_chunks.swap(pk_chunks);
-            P.pk_max_pairs = pk_max_pairs;
+            P.items.swap(pk.items);
+            P.pk_chunks.swap(pk.chunks);
+            P.pk_max_pairs = pk.max_pairs;
             P.pk_n_q = (uint32_t)n_q_frames;
-            rc = ensure_dev(P.d_pk_tab, P.d_pk_tab_n, tab.size()); if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(P.d_pk_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice, h->stream));
+            rc = ensure_dev(P.d_pk_tab, P.d_pk_tab_n, pk.tab.size()); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(P.d_pk_tab, pk.tab.data(), sizeof(uint32_t) * pk.tab.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));       // `tab` is a local: consumed before any early return below
         } else {
             // heaviest query frames first so the tail of the launch is made of short items
             for (int c = n_q_frames - 1; c >= 0; --c) {
@@ -163,7 +215,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
             rc = ensure_dev(P.d_items, P.d_items_cap, P.items.size()); if (rc) return rc;
             HIP_TRY(hipMemcpyAsync(P.d_items, P.items.data(), sizeof(lcm::WorkItem) * P.items.size(), hipMemcpyHostToDevice, h->stream));
         }
-        HIP_TRY(hipStreamSynchronize(h->stream));           // `tab` is a local
+        HIP_TRY(hipStreamSynchronize(h->stream));
         P.key = key;
     }
     *n_pairs = P.n_pairs;
@@ -213,40 +265,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     a.idx_sums = d_idx_sums;             // non-NULL: the argmin kernel (variant 1) runs whatever the handle's variant
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
     const int variant = d_idx_sums ? 1 : h->variant;
-    if (P.packed) {
-        // score kernel (per-row best distance / key of every eligible pair) + fold kernel, chunk by chunk on one stream:
-        // the fold of chunk k is done with the scratch before the scores of chunk k + 1 are written
-        const bool argmin = (variant == 1);
-        rc = ensure_dev(h->d_mdist, h->d_mdist_n, P.pk_max_pairs * (size_t)lcm::MAX_FUSED_QUERY_ROWS); if (rc) return rc;
-        HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-        uint32_t launches = 0, biggest = 0;
-        for (const Plan::PackedChunk& ch : P.pk_chunks) {
-            a.items = P.d_items + ch.item0;
-            a.pk_vstart = P.d_pk_tab + ch.tab0;
-            a.pk_qframe = a.pk_vstart + ch.n_pos + 1;
-            a.pk_elig = a.pk_qframe + ch.n_pos;
-            a.pk_pairs = a.pk_elig + ch.n_pos;
-            a.pk_dist = h->d_mdist; a.pk_n = ch.n_pos;
-            hipError_t e = lcm::launch_score_packed(a, ch.n_items, argmin, h->stream);
-            if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-            lcm::FinalizeBulkArgs f{};
-            f.key_shift = argmin ? lcm::KEY_SHIFT : 0; f.idx_sums = d_idx_sums;
-            f.dist = h->d_mdist; f.offsets = P.d_pk_tab; f.nq = reinterpret_cast<const int32_t*>(P.d_pk_tab + P.pk_n_q + 1);
-            f.db_counts = h->d_counts; f.scores = d_scores; f.n_q = P.pk_n_q; f.pair_base = ch.pair_base;
-            f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
-            const bool last = (&ch == &P.pk_chunks.back());      // the last chunk's fold is timed by itself (aux_kernel_ms)
-            if (last) HIP_TRY(hipEventRecord(h->ev_aux_start, h->stream));
-            e = lcm::launch_finalize_bulk(f, ch.n_pairs, h->stream);
-            if (e != hipSuccess) return fail(LCM_ERR_HIP, "fold kernel launch failed: %s", hipGetErrorString(e));
-            if (last) { HIP_TRY(hipEventRecord(h->ev_aux_stop, h->stream)); h->aux_pending = true; }
-            launches += 2; biggest = std::max(biggest, ch.n_items);
-        }
-        HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
-        h->info_pending = true;
-        h->info.launches = launches; h->info.workgroups = biggest; h->info.route = LCM_ROUTE_PACKED;
-        h->info.pairs = P.n_pairs; h->info.distances = P.distances; h->info.algo_bytes = P.algo_bytes;
-        return LCM_OK;
-    }
+    if (P.packed) return launch_packed(h, P, a, variant == 1, d_scores, d_idx_sums);
     // Very large searches go out as several launches (<= 2^20 work items, a few seconds each): no single kernel runs
     // long enough to meet a compute-queue timeout, and the stream stays responsive.
     constexpr size_t MAX_ITEMS_PER_LAUNCH = 1u << 20;
