@@ -35,6 +35,9 @@ LCM_API int  lcs_get_consecutive_matches(const lcs_system* s, lcm_dmatch* out, i
  * (README.md:101 "Re-match features on identified loop frames"); lists back to back in `out`, bounds in offsets. */
 LCM_API int  lcs_match_loop_closures(lcs_system* s, int current_frame_id, lcm_dmatch* out, size_t cap, size_t* offsets,
                                      int offsets_cap, int* n_lists);
+/* setGapByPosition: count "min_loop_gap frames ago" (README.md:122) on arrival positions — the reading of the tree's own
+ * loop, src/main.cpp:1375-1379 — instead of frame ids (default; identical for dense ids).  Before the first frame only. */
+LCM_API int  lcs_set_gap_by_position(lcs_system* s, int on);
 LCM_API int  lcs_num_frames(const lcs_system* s);                       /* getFrames().size()        hpp:60 */
 LCM_API int  lcs_num_loop_closures(const lcs_system* s);                /* getLoopClosures().size()  hpp:63 */
 LCM_API int  lcs_get_loop_closures(const lcs_system* s, lcm_loop_candidate* out, int cap, int* n_out);

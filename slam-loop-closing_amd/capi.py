@@ -632,6 +632,7 @@ _HOST_SIGNATURES = {
     "lcs_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i32p]),
     "lcs_get_consecutive_matches": (C.c_int, [_vp, _vp, C.c_int, _i32p]),
     "lcs_match_loop_closures": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_int, _i32p]),
+    "lcs_set_gap_by_position": (C.c_int, [_vp, C.c_int]),
     "lcs_num_frames": (C.c_int, [_vp]),
     "lcs_num_loop_closures": (C.c_int, [_vp]),
     "lcs_get_loop_closures": (C.c_int, [_vp, _vp, C.c_int, _i32p]),
@@ -704,6 +705,10 @@ class LoopClosingSystem:
         self._hcheck(self._lib.lcs_match_loop_closures(self._s, current_frame_id, out.ctypes.data_as(_vp), cap,
                                                        offs.ctypes.data_as(_vp), len(offs), C.byref(n)))
         return [out[int(offs[i]): int(offs[i + 1])] for i in range(n.value)]
+
+    def setGapByPosition(self, on: bool = True):
+        """Count min_loop_gap on arrival positions (the tree's own loop, src/main.cpp:1375-1379) instead of frame ids."""
+        self._hcheck(self._lib.lcs_set_gap_by_position(self._s, 1 if on else 0))
 
     def numFrames(self) -> int:
         return self._lib.lcs_num_frames(self._s)

@@ -45,6 +45,11 @@ LoopClosingSystem::~LoopClosingSystem() {
     else lcm_destroy(matcher_);
 }
 
+void LoopClosingSystem::setGapByPosition(bool on) {
+    if (!frames_.empty()) throw std::invalid_argument("setGapByPosition: only before the first frame is processed");
+    gap_by_position_ = on;
+}
+
 const Frame* LoopClosingSystem::findFrame(int frame_id) const {
     auto it = std::lower_bound(frames_.begin(), frames_.end(), frame_id, [](const Frame& f, int id) { return f.id < id; });
     return (it != frames_.end() && it->id == frame_id) ? &*it : nullptr;
@@ -71,9 +76,9 @@ void LoopClosingSystem::processFrame(const uint8_t* descriptors, int rows, int n
         const size_t pos = frames_.size() - 1;
         const Frame& s = frames_.back();
         if (group_) {
-            if (lcm_group_append(group_, s.id, s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_group_append");
+            if (lcm_group_append(group_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_group_append");
         } else if (ownsPosition(pos)) {
-            if (lcm_db_append(matcher_, s.id, s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_db_append");
+            if (lcm_db_append(matcher_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_db_append");
         }
     } catch (...) {
         // strong guarantee: a frame that could not be processed leaves no trace (host list, loop list, device DB agree)
@@ -103,12 +108,15 @@ std::vector<LoopCandidate> LoopClosingSystem::detectLoops(int current_frame_id) 
     int n = 0;
     static const uint8_t dummy[32] = {0};
     const uint8_t* q = cur->rows() > 0 ? cur->descriptors.data() : dummy;
-    const int rc = group_ ? lcm_group_detect_loops(group_, current_frame_id, q, cur->rows(), cur->num_keypoints,
+    const int key = keyOf((size_t)(cur - frames_.data()));       // the frame's id, or its arrival position (setGapByPosition)
+    const int rc = group_ ? lcm_group_detect_loops(group_, key, q, cur->rows(), cur->num_keypoints,
                                                    reinterpret_cast<lcm_loop_candidate*>(out.data()), cap, &n)
-                          : lcm_detect_loops(matcher_, current_frame_id, q, cur->rows(), cur->num_keypoints,
+                          : lcm_detect_loops(matcher_, key, q, cur->rows(), cur->num_keypoints,
                                              reinterpret_cast<lcm_loop_candidate*>(out.data()), cap, &n);
     if (rc != LCM_OK) raise("detectLoops");
     out.resize((size_t)n);
+    if (gap_by_position_)                                        // report the caller's frame ids, whatever keys the database
+        for (LoopCandidate& c : out) { c.current_frame_id = current_frame_id; c.matched_frame_id = frames_[(size_t)c.matched_frame_id].id; }
     return out;
 }
 
@@ -129,8 +137,9 @@ std::vector<std::vector<DMatch>> LoopClosingSystem::matchLoopClosures(int curren
         std::vector<size_t> where;
         for (size_t i = 0; i < trains.size(); ++i) {
             const Frame* t = findFrame(trains[i]);
-            const size_t pos = t ? (size_t)(t - frames_.data()) : 0;
-            if (!group_ || (int)(pos % (size_t)world) == r) { mine.push_back(trains[i]); where.push_back(i); }
+            if (!t) throw std::out_of_range("matchLoopClosures: a recorded loop closure names an unknown frame");
+            const size_t pos = (size_t)(t - frames_.data());
+            if (!group_ || (int)(pos % (size_t)world) == r) { mine.push_back(keyOf(pos)); where.push_back(i); }
         }
         if (mine.empty()) continue;
         lcm_handle* h = matcher_;
@@ -256,6 +265,11 @@ int lcs_match_loop_closures(lcs_system* s, int current_frame_id, lcm_dmatch* out
         offsets[lists.size()] = k;
         *n_lists = (int)lists.size();
     });
+}
+
+int lcs_set_gap_by_position(lcs_system* s, int on) {
+    if (!s) return LCM_ERR_INVALID_ARG;
+    return guarded([&] { s->sys.setGapByPosition(on != 0); });
 }
 
 int lcs_num_frames(const lcs_system* s) { return s ? (int)s->sys.getFrames().size() : 0; }

@@ -87,6 +87,15 @@ public:
     // Save results to file (hpp:66): writes <output_dir>/loop_closures.txt in the README's format (README.md:142-165).
     void saveResults(const std::string& output_dir);
 
+    // How "at least min_loop_gap frames ago" (README.md:122) is counted.  Default (false): on frame IDS, c.id - p.id >=
+    // min_loop_gap — the reading of the C ABI (include/lcm.h).  true: on ARRIVAL POSITIONS, the c-th processed frame
+    // against the frames processed at least min_loop_gap frames before it — the reading of the tree's own loop
+    // (src/main.cpp:1375-1379, `past <= curr - loopGap` over keyframe indices).  The two coincide for dense ids
+    // 0, 1, 2, ... and differ for sparse ones (video frame numbers with frame_skip = 3).  The device database is then
+    // keyed by position; every id this class reports is still the caller's frame id.  Only before the first frame.
+    void setGapByPosition(bool on);
+    bool gapByPosition() const { return gap_by_position_; }
+
     double loopThreshold() const { return loop_threshold_; }
     int minLoopGap() const { return min_loop_gap_; }
     const Frame* findFrame(int frame_id) const;
@@ -101,6 +110,8 @@ private:
     double loop_threshold_;              // hpp:75
     int min_loop_gap_;                   // hpp:76
     int shard_rank_, shard_world_;
+    bool gap_by_position_ = false;
+    int keyOf(size_t position) const { return gap_by_position_ ? (int)position : frames_[position].id; }   // the matcher's id of a frame
 };
 
 using LoopClosing = LoopClosingSystem;   // north_star's spelling of the class

@@ -122,3 +122,45 @@ def test_sharded_loop_search_driver_world1(pkg, oracle):
         op = oracle.default_params(min_gap=4)
         want = [t for c in range(fs.n_frames) for t in fast_detect_loops(oracle, fs, c, op)]
         assert got == want and len(want) > 0
+
+
+def test_gap_by_position_with_sparse_frame_ids(pkg, oracle):
+    """setGapByPosition: "at least min_loop_gap frames ago" counted on arrival positions — the tree's own loop,
+    src/main.cpp:1375-1379 — vs on frame ids (default).  With ids 0, 3, 6, ... (frame_skip = 3 video numbers) the two
+    readings select different frame sets; each must equal the oracle run with the matching key (ids, or positions)."""
+    fs = pkg.synth.make_frames(36, 300, seed=5, ragged=True, dup_frac=0.3)
+    fs.rows[20] = fs.rows[17]; fs.counts[20] = fs.counts[17]      # a revisit 3 frames later: a loop by id (9 >= 6), not by position
+    gap, thr = 6, 0.05
+    sparse_ids = (np.arange(fs.n_frames) * 3).astype(np.int32)
+    results = {}
+    for by_pos in (False, True):
+        sys_ = pkg.LoopClosingSystem(thr, gap)
+        try:
+            if by_pos:
+                sys_.setGapByPosition(True)
+            for f in range(fs.n_frames):
+                sys_.processFrame(fs.frame(f), int(sparse_ids[f]))
+            if by_pos:
+                with pytest.raises(pkg.capi.LcmError):
+                    sys_.setGapByPosition(False)               # only before the first frame
+            got = sys_.getLoopClosures()
+            results[by_pos] = {(int(r["current_frame_id"]), int(r["matched_frame_id"]), int(r["num_matches"])) for r in got}
+            # the oracle keyed the same way: ids (sparse) or positions; reported ids are always the caller's
+            keys = np.arange(fs.n_frames, dtype=np.int32) if by_pos else sparse_ids
+            p50 = oracle.default_params(min_gap=gap, sim_threshold=thr)
+            want = set()
+            for c in range(fs.n_frames):
+                for r in oracle.detect_loops(fs.rows, fs.counts, keys, c, p50):
+                    matched_pos = int(np.searchsorted(keys, int(r["matched_frame_id"])))
+                    want.add((int(sparse_ids[c]), int(sparse_ids[matched_pos]), int(r["num_matches"])))
+            assert results[by_pos] == want
+            if len(got):
+                c = int(got["current_frame_id"][-1])
+                lists = sys_.matchLoopClosures(c)
+                mine = got[got["current_frame_id"] == c]
+                for rec, lst in zip(mine, lists):
+                    assert len(lst) == int(rec["num_matches"])
+        finally:
+            sys_.close()
+    # by id: frame c sees ids <= 3c - 6 = positions <= c - 2; by position: positions <= c - 6 — a strict subset
+    assert results[True] < results[False] and (60, 51, int(fs.counts[17])) in results[False] - results[True]
