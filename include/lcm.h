@@ -326,7 +326,8 @@ LCM_API int  lcm_merge_shard_scores_device(lcm_handle* h, const void* d_gathered
  *   LCM_TUNE_ITEM_SLOTS   stored frames per work item of the bulk search, 1..64; 0 = automatic
  *   LCM_TUNE_ONLINE_SPLIT query rows per lane of the online split mode: 1, 2, 4; 0 = never split; -1 = automatic
  *   LCM_TUNE_PACKED       bulk search with the query rows of consecutive frames packed into full 2048-row workgroups:
- *                         1 = always, 0 = never, -1 = automatic (when packing saves lane slots)
+ *                         1 = always, 0 = never, -1 = automatic (when packing saves lane slots), 2 = always, with
+ *                         1536-row workgroups (6 rows per lane at 8 waves per SIMD: an A/B, within 0.5 % of 1)
  *   LCM_TUNE_ONLINE_STREAMS 1 (default) = each of the 4 query slots enqueues on its own stream, so consecutive online
  *                         queries overlap (upload and first workgroups of one under the draining tail of the other);
  *                         0 = everything on the handle's stream */

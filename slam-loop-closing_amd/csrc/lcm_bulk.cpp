@@ -16,9 +16,8 @@ struct PackedPlan {
 };
 
 int build_packed_plan(const std::vector<size_t>& offsets, const std::vector<int32_t>& qn, const uint32_t* q_frame_of, int chunk,
-                      PackedPlan& pk) {
+                      uint32_t COL, PackedPlan& pk) {
     constexpr size_t PK_CHUNK_PAIRS = 1u << 20;
-    constexpr uint32_t COL = (uint32_t)lcm::MAX_FUSED_QUERY_ROWS;
     const int n_q = (int)qn.size();
     auto elig_of = [&](int c) { return (uint32_t)(offsets[(size_t)c + 1] - offsets[(size_t)c]); };
     pk.tab.resize((size_t)n_q * 2 + 1);
@@ -82,7 +81,7 @@ int launch_packed(lcm_handle* h, const Plan& P, lcm::ScoreArgs a, bool argmin, v
         a.pk_qframe = a.pk_vstart + ch.n_pos + 1;
         a.pk_elig = a.pk_qframe + ch.n_pos;
         a.pk_pairs = a.pk_elig + ch.n_pos;
-        a.pk_dist = h->d_mdist; a.pk_n = ch.n_pos;
+        a.pk_dist = h->d_mdist; a.pk_n = ch.n_pos; a.pk_col_rows = P.pk_col_rows;
         hipError_t e = lcm::launch_score_packed(a, ch.n_items, argmin, h->stream);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         lcm::FinalizeBulkArgs f{};
@@ -188,11 +187,12 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
         // ---- packed form (ScoreArgs::pk_*): built beside the accounting, adopted when it saves lane slots
         PackedPlan pk;
         if (pack_ok && total > 0) {
-            rc = build_packed_plan(P.offsets, qn, q_frame_of, chunk, pk); if (rc) return rc;
+            P.pk_col_rows = h->tune_packed == 2 ? 1536u : (uint32_t)lcm::MAX_FUSED_QUERY_ROWS;
+            rc = build_packed_plan(P.offsets, qn, q_frame_of, chunk, P.pk_col_rows, pk); if (rc) return rc;
             const uint64_t shape_rows = P.max_q_rows <= 512 ? 512 : P.max_q_rows <= 1024 ? 1024 : P.max_q_rows <= 1536 ? 1536 : 2048;
             const uint64_t lanes_plain = (uint64_t)total * shape_rows;
             // automatic: worth it when it saves >= 1 % of the lane slots of a search big enough to be throughput-bound
-            P.packed = h->tune_packed == 1 || (total >= 8192 && pk.lane_slots * 100 <= lanes_plain * 99);
+            P.packed = h->tune_packed >= 1 || (total >= 8192 && pk.lane_slots * 100 <= lanes_plain * 99);
         }
         if (P.packed) {
             P.items.swap(pk.items);

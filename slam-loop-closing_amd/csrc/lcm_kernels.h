@@ -66,6 +66,7 @@ struct ScoreArgs {
     const uint32_t* pk_pairs;
     uint32_t*       pk_dist;
     uint32_t        pk_n;
+    uint32_t        pk_col_rows;  // rows per column (workgroup): 2048 (8 rows per lane) or 1536 (6 rows per lane)
     uint32_t        imp_nbatch;
     uint32_t        bat_wg[MAX_QUERY_BATCH + 1];
     uint32_t        bat_pair[MAX_QUERY_BATCH + 1];

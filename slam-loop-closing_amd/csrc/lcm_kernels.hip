@@ -163,7 +163,7 @@ constexpr int ARGMIN_GROUP = 16;      // train rows per (dist, group) key; a mul
 // (best distance, or best key in the argmin mode) — skipped where the stored frame is not eligible for that row's
 // query frame (the frames are packed by descending eligibility, so that is the last few slots of a column only).
 template <int THREADS, int QPT, int ARGMIN_MODE, bool WRITE_KEYS, bool PACKED = false>
-__global__ __launch_bounds__(THREADS, 6) void k_score_rowlane(ScoreArgs a) {
+__global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : 6) void k_score_rowlane(ScoreArgs a) {
     // ARGMIN_MODE = 0 with WRITE_KEYS = true writes the best DISTANCE per query row (split mode, see k_finalize_pairs)
     constexpr bool ARGMIN = ARGMIN_MODE != 0;
     constexpr bool GROUPED = ARGMIN_MODE == 1;
@@ -641,6 +641,11 @@ hipError_t launch_finalize(const FinalizeArgs& a, uint32_t n_pairs, hipStream_t 
 
 hipError_t launch_score_packed(const ScoreArgs& a, uint32_t n_items, bool argmin, hipStream_t st) {
     if (n_items == 0) return hipSuccess;
+    if (a.pk_col_rows == 1536) {          // EXPERIMENT: 6 rows per lane, 8 waves per SIMD
+        if (argmin) hipLaunchKernelGGL((k_score_rowlane<256, 6, 1, false, true>), dim3(n_items), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_score_rowlane<256, 6, 0, false, true>), dim3(n_items), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (argmin) hipLaunchKernelGGL((k_score_rowlane<256, 8, 1, false, true>), dim3(n_items), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_score_rowlane<256, 8, 0, false, true>), dim3(n_items), dim3(256), 0, st, a);
     return hipGetLastError();

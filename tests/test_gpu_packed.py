@@ -64,12 +64,12 @@ def test_packed_self_search_is_bit_exact(matcher, oracle, pkg, n_frames, max_des
         want, wsums, woffs = _want(oracle, fs, fs.ids, fs.rows, fs.counts, p)
         n, offs = matcher.all_vs_all_plan()
         assert n == len(want) and np.array_equal(offs.astype(np.int64), woffs)
-        for mode in (1, 0, -1):
+        for mode in (1, 0, -1, 2):                       # 2 = packed with 1536-row columns (6 rows per lane, 8 waves per SIMD)
             got, got2, sums, launches = _run(matcher, pkg, n, mode)
             np.testing.assert_array_equal(got, want, err_msg=f"packed={mode}")
             np.testing.assert_array_equal(got2, want, err_msg=f"packed={mode} (argmin kernel)")
             np.testing.assert_array_equal(sums, wsums, err_msg=f"packed={mode} (index checksums)")
-            if mode == 1:
+            if mode in (1, 2):
                 assert launches == pkg.capi.ROUTE_PACKED      # score + fold kernels: the packed route really ran
             if mode == 0:
                 assert launches == pkg.capi.ROUTE_PLAIN

@@ -32,7 +32,7 @@ def main():
         n, _ = m.all_vs_all_plan()
         d, ds = m.dev_alloc(n * 8), m.dev_alloc(n * 4)
         ref = None
-        for packed in (0, 1):
+        for packed in (0, 1, 2):
             for slots in [int(x) for x in args.slots.split(",")]:
                 m.set_tuning(pkg.capi.TUNE_PACKED, packed)
                 m.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, slots)
