@@ -92,7 +92,17 @@ def cpu_baseline_sample(entry, pkg, fs, gap, offs, got, seconds, threads, shard=
     n_s = int(min(len(qs), max(n_cal, seconds / max(secs / n_cal, 1e-9))))
     cs, secs, isa = oracle.fast_score_pairs(fs.rows, fs.counts, qs[:n_s], ts[:n_s], op, threads)
     cpu_dist = int(np.sum(fs.counts[qs[:n_s]].astype(np.int64) * fs.counts[ts[:n_s]].astype(np.int64)))
-    out = {"value": cpu_dist / secs, "unit": "distances/s", "cores": threads, "kind": "port",
+    # the scalar restatement (Part 1 of the oracle: the plain, deliberately untuned statement of the rules, one thread,
+    # ~1 s per 2000 x 2000 pair) on three of the same pairs: the semantic reference's own speed, and a check that the
+    # tuned path's records are its records
+    n_sc = min(3, n_s)
+    t_sc = time.perf_counter()
+    sc_recs = [oracle.pair_score(fs.frame(int(q)), fs.frame(int(t)), op) for q, t in zip(qs[:n_sc], ts[:n_sc])]
+    t_sc = time.perf_counter() - t_sc
+    sc_dist = int(np.sum(fs.counts[qs[:n_sc]].astype(np.int64) * fs.counts[ts[:n_sc]].astype(np.int64)))
+    scalar = {"value": sc_dist / max(t_sc, 1e-9), "unit": "distances/s", "cores": 1, "pairs": int(n_sc),
+              "equals_tuned_path": bool(all(sc_recs[k] == cs[k] for k in range(n_sc)))}
+    out = {"value": cpu_dist / secs, "unit": "distances/s", "cores": threads, "kind": "port", "scalar_oracle_1_thread": scalar,
            "sample": f"{n_s} random eligible pairs of the same workload ({cpu_dist:.3e} distances, {secs:.1f} s), "
                      f"oracle tuned path ({isa}, pthreads over pairs)"}
     if got is not None:
