@@ -20,6 +20,9 @@ KEY_SHIFT = 22
 TUNE_ITEM_SLOTS, TUNE_ONLINE_SPLIT, TUNE_PACKED, TUNE_ONLINE_STREAMS = 0, 1, 2, 3      # lcm_tuning
 
 
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_ORDER, ERR_NOT_FOUND, ERR_OOM = 0, -1, -2, -3, -4, -5, -6, -7   # lcm_status
+
+
 class LcmError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"lcm error {code}: {msg}")

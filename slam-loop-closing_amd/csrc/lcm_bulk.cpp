@@ -16,8 +16,8 @@ struct PackedPlan {
 };
 
 int build_packed_plan(const std::vector<size_t>& offsets, const std::vector<int32_t>& qn, const uint32_t* q_frame_of, int chunk,
-                      uint32_t COL, PackedPlan& pk) {
-    constexpr size_t PK_CHUNK_PAIRS = 1u << 20;
+                      uint32_t COL, uint32_t stride, PackedPlan& pk) {
+    const size_t PK_CHUNK_PAIRS = std::max<size_t>(1, ((size_t)1 << 31) / stride);      // 8 GiB of scratch words per chunk
     const int n_q = (int)qn.size();
     auto elig_of = [&](int c) { return (uint32_t)(offsets[(size_t)c + 1] - offsets[(size_t)c]); };
     pk.tab.resize((size_t)n_q * 2 + 1);
@@ -72,7 +72,7 @@ int build_packed_plan(const std::vector<size_t>& offsets, const std::vector<int3
 // Packed route: score kernel (per-row best distance / key of every eligible pair) + fold kernel, chunk by chunk on one
 // stream: the fold of chunk k is done with the scratch before the scores of chunk k + 1 are written.
 int launch_packed(lcm_handle* h, const Plan& P, lcm::ScoreArgs a, bool argmin, void* d_scores, uint32_t* d_idx_sums) {
-    int rc = ensure_dev(h->d_mdist, h->d_mdist_n, P.pk_max_pairs * (size_t)lcm::MAX_FUSED_QUERY_ROWS); if (rc) return rc;
+    int rc = ensure_dev(h->d_mdist, h->d_mdist_n, P.pk_max_pairs * (size_t)P.pk_stride); if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_start, h->stream));
     uint32_t launches = 0, biggest = 0;
     for (const Plan::PackedChunk& ch : P.pk_chunks) {
@@ -81,11 +81,11 @@ int launch_packed(lcm_handle* h, const Plan& P, lcm::ScoreArgs a, bool argmin, v
         a.pk_qframe = a.pk_vstart + ch.n_pos + 1;
         a.pk_elig = a.pk_qframe + ch.n_pos;
         a.pk_pairs = a.pk_elig + ch.n_pos;
-        a.pk_dist = h->d_mdist; a.pk_n = ch.n_pos; a.pk_col_rows = P.pk_col_rows;
+        a.pk_dist = h->d_mdist; a.pk_n = ch.n_pos; a.pk_col_rows = P.pk_col_rows; a.pk_stride = P.pk_stride;
         hipError_t e = lcm::launch_score_packed(a, ch.n_items, argmin, h->stream);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         lcm::FinalizeBulkArgs f{};
-        f.key_shift = argmin ? lcm::KEY_SHIFT : 0; f.idx_sums = d_idx_sums;
+        f.stride = P.pk_stride; f.key_shift = argmin ? lcm::KEY_SHIFT : 0; f.idx_sums = d_idx_sums;
         f.dist = h->d_mdist; f.offsets = P.d_pk_tab; f.nq = reinterpret_cast<const int32_t*>(P.d_pk_tab + P.pk_n_q + 1);
         f.db_counts = h->d_counts; f.scores = d_scores; f.n_q = P.pk_n_q; f.pair_base = ch.pair_base;
         f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
@@ -127,7 +127,6 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     } else if (!d_query_counts || !q_ids || n_q_frames < 0 || q_stride_rows <= 0) {
         return fail(LCM_ERR_INVALID_ARG, "external query set needs counts, ids and a stride");
     }
-    if (q_stride_rows > lcm::MAX_FUSED_QUERY_ROWS && !self) return fail(LCM_ERR_CAPACITY, "query frames may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
 
     // ---- plan (cached while the database, the query-id list AND the query frames' row counts are unchanged)
     // The row counts of an external query set live on the device and may change between calls with the same ids, and
@@ -182,17 +181,23 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
                 P.max_q_rows = std::max(P.max_q_rows, (int)qn[(size_t)c]);
             }
         }
-        if (P.max_q_rows > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "query frames may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+        // Query frames above 2048 rows (ORB with nfeatures > 2048) do not fit one workgroup's registers: only the packed
+        // route serves them (a frame then spans several 2048-row columns), so it is taken whatever its size.
+        const bool big_rows = P.max_q_rows > lcm::MAX_FUSED_QUERY_ROWS;
+        if (big_rows && !pack_ok)
+            return fail(LCM_ERR_CAPACITY, "query frames above %d rows need the packed bulk route (not with cross_check, kernel variants 2 / 3 or LCM_TUNE_PACKED = 0)", lcm::MAX_FUSED_QUERY_ROWS);
 
         // ---- packed form (ScoreArgs::pk_*): built beside the accounting, adopted when it saves lane slots
         PackedPlan pk;
         if (pack_ok && total > 0) {
             P.pk_col_rows = h->tune_packed == 2 ? 1536u : (uint32_t)lcm::MAX_FUSED_QUERY_ROWS;
-            rc = build_packed_plan(P.offsets, qn, q_frame_of, chunk, P.pk_col_rows, pk); if (rc) return rc;
+            // scratch words per pair: 2048, or the largest query frame (rounded up) when frames exceed that
+            P.pk_stride = big_rows ? (uint32_t)round_up(P.max_q_rows, 256) : (uint32_t)lcm::MAX_FUSED_QUERY_ROWS;
+            rc = build_packed_plan(P.offsets, qn, q_frame_of, chunk, P.pk_col_rows, P.pk_stride, pk); if (rc) return rc;
             const uint64_t shape_rows = P.max_q_rows <= 512 ? 512 : P.max_q_rows <= 1024 ? 1024 : P.max_q_rows <= 1536 ? 1536 : 2048;
             const uint64_t lanes_plain = (uint64_t)total * shape_rows;
             // automatic: worth it when it saves >= 1 % of the lane slots of a search big enough to be throughput-bound
-            P.packed = h->tune_packed >= 1 || (total >= 8192 && pk.lane_slots * 100 <= lanes_plain * 99);
+            P.packed = big_rows || h->tune_packed >= 1 || (total >= 8192 && pk.lane_slots * 100 <= lanes_plain * 99);
         }
         if (P.packed) {
             P.items.swap(pk.items);
@@ -250,7 +255,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
         }
         return cross_score_prefixes(h, qbase, row0.data(), nqv.data(), ev.data(), n_q_frames, (lcm_score*)d_scores, d_idx_sums);
     }
-    if ((h->variant == 4 || h->variant == 5) && !d_idx_sums) {
+    if ((h->variant == 4 || h->variant == 5) && !d_idx_sums && P.max_q_rows <= lcm::MAX_FUSED_QUERY_ROWS) {      // (bigger query frames: packed vector-ALU route)
         std::vector<int> nqv((size_t)n_q_frames);
         for (int c = 0; c < n_q_frames; ++c) nqv[(size_t)c] = self ? h->frames[(size_t)c].n : qc[(size_t)c];
         return mfma_bulk(h, self, self ? h->d_rows : (const uint8_t*)d_query_rows, d_query_counts,

@@ -315,7 +315,6 @@ int lcm_group_all_vs_all(lcm_group* g, lcm_score* out_scores, size_t cap, size_t
         int stride = 4;
         for (lcm_handle* h : g->h) stride = std::max(stride, h->stride_rows);
         for (const GFrame& f : g->frames) stride = std::max(stride, (f.n + 3) / 4 * 4);
-        if (stride > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "query frames may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
         for (int r = 0; r < W; ++r) {
             int rc = lcm_db_reserve(g->h[(size_t)r], shard_cap, stride); if (rc) return rc;
             rc = lcm_sync(g->h[(size_t)r]); if (rc) return rc;               // every append has landed

@@ -118,6 +118,7 @@ struct Plan {            // cached work list of one bulk call shape
     size_t pk_max_pairs = 0;        // largest chunk: sizes the per-row scratch (8 KB per pair)
     uint32_t pk_n_q = 0;
     uint32_t pk_col_rows = 2048;    // rows per column = rows per workgroup of the packed score kernel
+    uint32_t pk_stride = 2048;      // scratch words per pair
 };
 
 }  // namespace lcm

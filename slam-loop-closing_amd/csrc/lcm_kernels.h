@@ -59,7 +59,8 @@ struct ScoreArgs {
     // workgroup index w in that space (virtual rows [2048 w, 2048 w + 2048)), slots as usual.  Per query frame c of the
     // chunk (pk_n of them): pk_vstart[c] = its first virtual row (pk_vstart[pk_n] = total), pk_qframe[c] = its index in
     // q_rows, pk_elig[c] = eligible stored slots, pk_pairs[c] = its first pair in pk_dist.  Output: the best distance
-    // (ARGMIN: packed key) of every (pair, query row) -> pk_dist[pair * 2048 + row]; launch_finalize_bulk folds them.
+    // (ARGMIN: packed key) of every (pair, query row) -> pk_dist[pair * pk_stride + row]; launch_finalize_bulk folds them.
+    // Query frames may exceed 2048 rows here (they span columns); every other route stops at MAX_FUSED_QUERY_ROWS.
     const uint32_t* pk_vstart;
     const uint32_t* pk_qframe;
     const uint32_t* pk_elig;
@@ -67,6 +68,7 @@ struct ScoreArgs {
     uint32_t*       pk_dist;
     uint32_t        pk_n;
     uint32_t        pk_col_rows;  // rows per column (workgroup): 2048 (8 rows per lane) or 1536 (6 rows per lane)
+    uint32_t        pk_stride;    // words of pk_dist per pair: 2048, or the largest query frame rounded up when above that
     uint32_t        imp_nbatch;
     uint32_t        bat_wg[MAX_QUERY_BATCH + 1];
     uint32_t        bat_pair[MAX_QUERY_BATCH + 1];
@@ -200,8 +202,9 @@ hipError_t launch_expand_fp4(const uint32_t* rows, const int32_t* counts, uint32
 hipError_t launch_score_mfma_fp4(const MfmaArgs& a, uint32_t n_items, hipStream_t st);
 
 // Pair p (global index, pair_base <= p < pair_base + n_pairs) belongs to query c = last c with offsets[c] <= p and is
-// stored slot p - offsets[c]; folds dist[(p - pair_base) * 2048 + r], r < nq[c], into the pair's score record.
+// stored slot p - offsets[c]; folds dist[(p - pair_base) * stride + r], r < nq[c], into the pair's score record.
 struct FinalizeBulkArgs {
+    uint32_t        stride;        // words of dist per pair (0 = MAX_FUSED_QUERY_ROWS); a multiple of 4
     int32_t         key_shift;     // 0: dist holds distances; KEY_SHIFT: packed keys dist << 22 | train row
     uint32_t*       idx_sums;      // optional (keys): per pair, sum of the good matches' train rows mod 2^32
     const uint32_t* dist;

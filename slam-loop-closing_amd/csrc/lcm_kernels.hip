@@ -158,8 +158,8 @@ constexpr int ARGMIN_GROUP = 16;      // train rows per (dist, group) key; a mul
 // PACKED (bulk search, 256 x 8 only): the workgroup owns 2048 consecutive rows of a VIRTUAL row space in which the
 // query frames of a chunk follow one another without gaps (ScoreArgs::pk_*), so a 2000-row ORB frame no longer leaves
 // 48 of the 2048 lane slots idle (measured worth: 2.5 %, profiles/r02_idle_lanes.txt).  A lane's 8 rows may then
-// belong to different query frames: each (lane, j) keeps `packed position << 11 | row in its frame` in a lane-private
-// LDS word, the per-pair reductions move to k_finalize_bulk, and the epilogue is 8 stores per lane per stored frame
+// belong to different query frames (and a frame above 2048 rows spans several workgroups): each (lane, j) keeps the
+// packed position of its row's frame in a lane-private LDS word, the per-pair reductions move to k_finalize_bulk, and the epilogue is 8 stores per lane per stored frame
 // (best distance, or best key in the argmin mode) — skipped where the stored frame is not eligible for that row's
 // query frame (the frames are packed by descending eligibility, so that is the last few slots of a column only).
 template <int THREADS, int QPT, int ARGMIN_MODE, bool WRITE_KEYS, bool PACKED = false>
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : 6) void k_score
     __shared__ uint32_t red_sum[2];
     __shared__ uint32_t red_idx[2];
     __shared__ uint32_t lane_key[GROUPED ? THREADS * QPT : 1];
-    __shared__ uint32_t lane_meta[PACKED ? THREADS * QPT : 1];     // PACKED: packed position << 11 | row, 0xFFFFFFFF = idle
+    __shared__ uint32_t lane_meta[PACKED ? THREADS * QPT : 1];     // PACKED: packed position of the row's frame, 0xFFFFFFFF = idle
 
     const int tid = threadIdx.x;
     if (tid == 0) { red_min[0] = red_min[1] = 0xFFFFFFFFu; red_sum[0] = red_sum[1] = 0u; red_idx[0] = red_idx[1] = 0u; }
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : 6) void k_score
             uint32_t meta = 0xFFFFFFFFu;
             if (j * THREADS + tid < nq) {
                 while (a.pk_vstart[c + 1] <= v) ++c;                // v < pk_vstart[pk_n]: stops at c < pk_n
-                const uint32_t r = v - a.pk_vstart[c];
+                const uint32_t r = v - a.pk_vstart[c];              // row inside its frame (a frame above 2048 rows spans columns)
                 const uint4* qb = reinterpret_cast<const uint4*>(a.q_rows + (size_t)a.pk_qframe[c] * a.q_stride_words);
-                lo = qb[r * 2]; hi = qb[r * 2 + 1];
-                meta = (c << 11) | r;
+                lo = qb[(size_t)r * 2]; hi = qb[(size_t)r * 2 + 1];
+                meta = c;
             }
             lane_meta[j * THREADS + tid] = meta;
             q[j][0] = lo.x; q[j][1] = lo.y; q[j][2] = lo.z; q[j][3] = lo.w;
@@ -332,10 +332,10 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : 6) void k_score
         if (PACKED) {        // best distance / key of every (eligible pair, query row); k_finalize_bulk forms the records
 #pragma unroll
             for (int j = 0; j < QPT; ++j) {
-                const uint32_t meta = lane_meta[j * THREADS + tid];
-                if (meta == 0xFFFFFFFFu) continue;
-                const uint32_t c = meta >> 11, r = meta & 2047u;
-                if (slot < a.pk_elig[c]) a.pk_dist[((size_t)a.pk_pairs[c] + slot) * MAX_FUSED_QUERY_ROWS + r] = best[j];
+                const uint32_t c = lane_meta[j * THREADS + tid];
+                if (c == 0xFFFFFFFFu) continue;
+                const uint32_t r = it.q_frame * (uint32_t)(THREADS * QPT) + (uint32_t)(j * THREADS + tid) - a.pk_vstart[c];
+                if (slot < a.pk_elig[c]) a.pk_dist[((size_t)a.pk_pairs[c] + slot) * a.pk_stride + r] = best[j];
             }
             continue;
         }

@@ -250,32 +250,47 @@ __global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a, uint3
     }
     const int nq = a.nq[lo];
     const uint32_t slot = p - a.offsets[lo];
-    const uint4* d = reinterpret_cast<const uint4*>(a.dist + (size_t)local * MAX_FUSED_QUERY_ROWS);
+    const uint32_t stride = a.stride ? a.stride : (uint32_t)MAX_FUSED_QUERY_ROWS;
+    const uint4* d = reinterpret_cast<const uint4*>(a.dist + (size_t)local * stride);
     const int sh = a.key_shift;
     const uint32_t idx_mask = sh ? ((1u << sh) - 1u) : 0u;
-    uint32_t v[32];
+    uint32_t dmin = 0xFFFFFFFFu, cnt = 0, isum = 0;
+    if (nq <= MAX_FUSED_QUERY_ROWS) {
+        uint32_t v[32];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r0 = (i * 64 + lane) * 4;                     // rows r0 .. r0 + 3; rows >= nq hold stale words: masked
-        uint4 x = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (r0 < nq) x = d[i * 64 + lane];
-        v[4 * i + 0] = x.x;
-        v[4 * i + 1] = r0 + 1 < nq ? x.y : 0xFFFFFFFFu;
-        v[4 * i + 2] = r0 + 2 < nq ? x.z : 0xFFFFFFFFu;
-        v[4 * i + 3] = r0 + 3 < nq ? x.w : 0xFFFFFFFFu;
-    }
-    uint32_t dmin = 0xFFFFFFFFu;
+        for (int i = 0; i < 8; ++i) {
+            const int r0 = (i * 64 + lane) * 4;                 // rows r0 .. r0 + 3; rows >= nq hold stale words: masked
+            uint4 x = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (r0 < nq) x = d[i * 64 + lane];
+            v[4 * i + 0] = x.x;
+            v[4 * i + 1] = r0 + 1 < nq ? x.y : 0xFFFFFFFFu;
+            v[4 * i + 2] = r0 + 2 < nq ? x.z : 0xFFFFFFFFu;
+            v[4 * i + 3] = r0 + 3 < nq ? x.w : 0xFFFFFFFFu;
+        }
 #pragma unroll
-    for (int k = 0; k < 32; ++k) dmin = min(dmin, v[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : v[k] >> sh);
+        for (int k = 0; k < 32; ++k) dmin = min(dmin, v[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : v[k] >> sh);
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
-    const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
-    uint32_t cnt = 0, isum = 0;
+        for (int o = 32; o >= 1; o >>= 1) dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+        const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        const bool good = v[k] != 0xFFFFFFFFu && (v[k] >> sh) <= thr;
-        cnt += good ? 1u : 0u;
-        isum += good ? (v[k] & idx_mask) : 0u;
+        for (int k = 0; k < 32; ++k) {
+            const bool good = v[k] != 0xFFFFFFFFu && (v[k] >> sh) <= thr;
+            cnt += good ? 1u : 0u;
+            isum += good ? (v[k] & idx_mask) : 0u;
+        }
+    } else {
+        // a query frame above 2048 rows (packed route only): two passes over its words, the second from the caches
+        const uint32_t* w = a.dist + (size_t)local * stride;
+        for (int r = lane; r < nq; r += 64) { const uint32_t x = w[r]; if (x != 0xFFFFFFFFu) dmin = min(dmin, x >> sh); }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+        const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
+        for (int r = lane; r < nq; r += 64) {
+            const uint32_t x = w[r];
+            const bool good = x != 0xFFFFFFFFu && (x >> sh) <= thr;
+            cnt += good ? 1u : 0u;
+            isum += good ? (x & idx_mask) : 0u;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { cnt += (uint32_t)__shfl_xor((int)cnt, o, 64); isum += (uint32_t)__shfl_xor((int)isum, o, 64); }

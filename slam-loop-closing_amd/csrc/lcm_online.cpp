@@ -203,6 +203,41 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
     return LCM_OK;
 }
 
+// Query frames above 2048 rows (ORB with nfeatures > 2048) do not fit one workgroup's registers: they go through the
+// bulk search's packed route (lcm_bulk.cpp) as an external query set of B frames — same records, same (query, slot)
+// order — on the handle's stream, with the bulk plan and scratch.  Throughput path of a rare shape, not a fast one.
+static int enqueue_big(lcm_handle* h, QuerySlot& q, const void* d_q, const int32_t* d_counts, int stride_rows, int B,
+                       const int* nq, const int* ids, const int* elig) {
+    size_t total = 0;
+    int max_nq = 0;
+    for (int b = 0; b < B; ++b) { total += (size_t)elig[b]; max_nq = std::max(max_nq, nq[b]); q.bat_elig[b] = elig[b]; }
+    q.n_elig = (int)total; q.nq = max_nq;
+    q.acc_pairs = q.acc_distances = q.acc_bytes = 0; q.acc_launches = 0; q.acc_queries = (uint32_t)B;
+    if (total == 0) { HIP_TRY(hipEventRecord(q.done, h->stream)); return LCM_OK; }
+    if (total > 0x7FFFFFFFull) return fail(LCM_ERR_CAPACITY, "more than 2^31 pairs in one batch");
+    int rc = ensure_dev(q.d_scores, q.d_scores_n, total); if (rc) return rc;
+    rc = ensure_pinned(q.h_scores, q.h_scores_n, total); if (rc) return rc;
+    HIP_TRY(hipEventRecord(q.k0, h->stream));
+    size_t n = 0;
+    rc = lcm::all_vs_all(h, d_q, d_counts, ids, B, stride_rows, q.d_scores, total, &n, nullptr, nullptr, nullptr, nq);
+    if (rc) return rc;
+    if (n != total) return fail(LCM_ERR_HIP, "internal: bulk route scored %zu pairs, the online path expected %zu", n, total);
+    HIP_TRY(hipEventRecord(q.k1, h->stream));
+    q.acc_pairs = h->info.pairs; q.acc_distances = h->info.distances; q.acc_bytes = h->info.algo_bytes; q.acc_launches = h->info.launches;
+    HIP_TRY(hipMemcpyAsync(q.h_scores, q.d_scores, sizeof(lcm_score) * total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(q.done, h->stream));
+    return LCM_OK;
+}
+
+// The per-query row counts of a big-frame submit, on the device (the bulk search reads them there)
+static int upload_counts(lcm_handle* h, QuerySlot& q, const int* nq, int B) {
+    int rc = ensure_pinned(q.h_meta, q.h_meta_bytes, sizeof(int32_t) * (size_t)lcm::MAX_QUERY_BATCH); if (rc) return rc;
+    rc = ensure_dev(q.d_meta, q.d_meta_bytes, sizeof(int32_t) * (size_t)lcm::MAX_QUERY_BATCH); if (rc) return rc;
+    memcpy(q.h_meta, nq, sizeof(int32_t) * (size_t)B);
+    HIP_TRY(hipMemcpyAsync(q.d_meta, q.h_meta, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    return LCM_OK;
+}
+
 // A finished query (its `done` event has been waited for) joins the handle's online totals.
 static void fold_online_stats(lcm_handle* h, QuerySlot& q) {
     if (q.acc_launches) {
@@ -250,7 +285,7 @@ static int pick_stream(lcm_handle* h, QuerySlot& q, hipStream_t* S) {
 static int query_submit_impl(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, int* ticket) {
     if (!h || nq < 0 || !ticket || (nq > 0 && !query)) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     *ticket = -1;
-    if (nq > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
+    const bool big = nq > lcm::MAX_FUSED_QUERY_ROWS;              // served by the bulk search's packed route (enqueue_big)
     int rc = set_device(h); if (rc) return rc;
     int t = -1;
     rc = acquire_query_slot(h, &t); if (rc) return rc;
@@ -263,14 +298,20 @@ static int query_submit_impl(lcm_handle* h, const uint8_t* query, int nq, int qu
     const size_t bytes = (size_t)std::max(rows_up, 1) * LCM_DESC_BYTES;
     rc = ensure_pinned(q.h_query, q.h_query_bytes, bytes); if (rc) return rc;
     rc = ensure_dev(q.d_query, q.d_query_bytes, bytes, ARENA_SLACK); if (rc) return rc;
-    hipStream_t S;
-    rc = pick_stream(h, q, &S); if (rc) return rc;
+    hipStream_t S = h->stream;
+    if (!big) { rc = pick_stream(h, q, &S); if (rc) return rc; }
     if (nq > 0 && n_elig > 0) {
         memcpy(q.h_query, query, (size_t)nq * LCM_DESC_BYTES);       // the caller's buffer is free when we return
         for (int r = nq; r < rows_up; ++r) memcpy(q.h_query + (size_t)r * LCM_DESC_BYTES, query + (size_t)(nq - 1) * LCM_DESC_BYTES, LCM_DESC_BYTES);
         HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, (size_t)rows_up * LCM_DESC_BYTES, hipMemcpyHostToDevice, S));
     }
-    rc = enqueue_query(h, q, (const uint32_t*)q.d_query, nq, n_elig, S); if (rc) return rc;
+    if (big) {
+        q.n_batch = 0;
+        rc = upload_counts(h, q, &nq, 1); if (rc) return rc;
+        rc = enqueue_big(h, q, q.d_query, reinterpret_cast<const int32_t*>(q.d_meta), rows_up, 1, &nq, &query_frame_id, &n_elig); if (rc) return rc;
+    } else {
+        rc = enqueue_query(h, q, (const uint32_t*)q.d_query, nq, n_elig, S); if (rc) return rc;
+    }
     q.busy = true;
     q.db_generation = h->db_generation;
     *ticket = t;
@@ -312,7 +353,6 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
     int max_nq = 0;
     for (int b = 0; b < n_queries; ++b) {
         if (nq[b] < 0 || (nq[b] > 0 && !queries[b])) return fail(LCM_ERR_INVALID_ARG, "query %d: bad rows", b);
-        if (nq[b] > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
         max_nq = std::max(max_nq, nq[b]);
     }
     int rc = set_device(h); if (rc) return rc;
@@ -339,8 +379,9 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
     const size_t bytes = (size_t)pitch * (size_t)n_queries * LCM_DESC_BYTES;
     rc = ensure_pinned(q.h_query, q.h_query_bytes, bytes); if (rc) return rc;
     rc = ensure_dev(q.d_query, q.d_query_bytes, bytes, ARENA_SLACK); if (rc) return rc;
-    hipStream_t S;
-    rc = pick_stream(h, q, &S); if (rc) return rc;
+    const bool big = max_nq > lcm::MAX_FUSED_QUERY_ROWS;          // served by the bulk search's packed route (enqueue_big)
+    hipStream_t S = h->stream;
+    if (!big) { rc = pick_stream(h, q, &S); if (rc) return rc; }
     if (total > 0) {
         for (int b = 0; b < n_queries; ++b)          // the callers' buffers are free when we return
             if (nq[b] > 0) {
@@ -351,7 +392,13 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
             }
         HIP_TRY(hipMemcpyAsync(q.d_query, q.h_query, bytes, hipMemcpyHostToDevice, S));
     }
-    rc = enqueue_batch(h, q, (const uint32_t*)q.d_query, pitch, n_queries, nq, elig, S); if (rc) return rc;
+    if (big) {
+        q.n_batch = n_queries;
+        rc = upload_counts(h, q, nq, n_queries); if (rc) return rc;
+        rc = enqueue_big(h, q, q.d_query, reinterpret_cast<const int32_t*>(q.d_meta), pitch, n_queries, nq, query_frame_ids, elig); if (rc) return rc;
+    } else {
+        rc = enqueue_batch(h, q, (const uint32_t*)q.d_query, pitch, n_queries, nq, elig, S); if (rc) return rc;
+    }
     q.busy = true;
     q.db_generation = h->db_generation;
     *ticket = t;
@@ -410,14 +457,19 @@ static int detect_loops_impl(lcm_handle* h, int current_frame_id, const uint8_t*
         if (slot < 0) return fail(LCM_ERR_NOT_FOUND, "frame id %d is not stored", current_frame_id);
         nq = h->frames[slot].n;
         q_kp = h->frames[slot].n_kp;
-        if (nq > lcm::MAX_FUSED_QUERY_ROWS) return fail(LCM_ERR_CAPACITY, "a query frame may hold at most %d rows", lcm::MAX_FUSED_QUERY_ROWS);
         rc = acquire_query_slot(h, &t); if (rc) return rc;
         QuerySlot& q = h->qslots[t];
         q.query_id = current_frame_id;
-        hipStream_t S;
-        rc = pick_stream(h, q, &S); if (rc) return rc;
-        rc = enqueue_query(h, q, (const uint32_t*)(h->d_rows + (size_t)slot * h->stride_rows * LCM_DESC_BYTES), nq,
-                           eligible_prefix(h, current_frame_id, h->params.min_gap), S);
+        const uint8_t* d_frame = h->d_rows + (size_t)slot * h->stride_rows * LCM_DESC_BYTES;
+        const int n_elig = eligible_prefix(h, current_frame_id, h->params.min_gap);
+        if (nq > lcm::MAX_FUSED_QUERY_ROWS) {       // a stored frame above 2048 rows as query: the bulk search's packed route
+            q.n_batch = 0;
+            rc = enqueue_big(h, q, d_frame, h->d_counts + slot, h->stride_rows, 1, &nq, &current_frame_id, &n_elig);
+        } else {
+            hipStream_t S;
+            rc = pick_stream(h, q, &S); if (rc) return rc;
+            rc = enqueue_query(h, q, (const uint32_t*)d_frame, nq, n_elig, S);
+        }
         if (rc) return rc;
         q.busy = true;
         q.db_generation = h->db_generation;
