@@ -285,6 +285,7 @@ static int pick_stream(lcm_handle* h, QuerySlot& q, hipStream_t* S) {
 static int query_submit_impl(lcm_handle* h, const uint8_t* query, int nq, int query_frame_id, int* ticket) {
     if (!h || nq < 0 || !ticket || (nq > 0 && !query)) return fail(LCM_ERR_INVALID_ARG, "bad argument");
     *ticket = -1;
+    if (nq > 65535) return fail(LCM_ERR_CAPACITY, "a frame may hold at most 65535 rows (got %d)", nq);
     const bool big = nq > lcm::MAX_FUSED_QUERY_ROWS;              // served by the bulk search's packed route (enqueue_big)
     int rc = set_device(h); if (rc) return rc;
     int t = -1;
@@ -353,6 +354,7 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
     int max_nq = 0;
     for (int b = 0; b < n_queries; ++b) {
         if (nq[b] < 0 || (nq[b] > 0 && !queries[b])) return fail(LCM_ERR_INVALID_ARG, "query %d: bad rows", b);
+        if (nq[b] > 65535) return fail(LCM_ERR_CAPACITY, "a frame may hold at most 65535 rows (query %d has %d)", b, nq[b]);
         max_nq = std::max(max_nq, nq[b]);
     }
     int rc = set_device(h); if (rc) return rc;
