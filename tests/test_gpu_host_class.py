@@ -149,10 +149,14 @@ def test_gap_by_position_with_sparse_frame_ids(pkg, oracle):
             keys = np.arange(fs.n_frames, dtype=np.int32) if by_pos else sparse_ids
             p50 = oracle.default_params(min_gap=gap, sim_threshold=thr)
             want = set()
+            fs_k = pkg.synth.FrameSet(rows=fs.rows, counts=fs.counts, ids=keys, seed=fs.seed)
             for c in range(fs.n_frames):
-                for r in oracle.detect_loops(fs.rows, fs.counts, keys, c, p50):
-                    matched_pos = int(np.searchsorted(keys, int(r["matched_frame_id"])))
-                    want.add((int(sparse_ids[c]), int(sparse_ids[matched_pos]), int(r["num_matches"])))
+                for (_, matched_key, good, _sim) in fast_detect_loops(oracle, fs_k, c, p50):
+                    matched_pos = int(np.searchsorted(keys, matched_key))
+                    want.add((int(sparse_ids[c]), int(sparse_ids[matched_pos]), good))
+            c0 = fs.n_frames - 1                                  # ... and the scalar restatement for one frame
+            assert {(int(sparse_ids[c0]), int(sparse_ids[int(np.searchsorted(keys, int(r["matched_frame_id"])))]), int(r["num_matches"]))
+                    for r in oracle.detect_loops(fs.rows, fs.counts, keys, c0, p50)} == {w for w in want if w[0] == int(sparse_ids[c0])}
             assert results[by_pos] == want
             if len(got):
                 c = int(got["current_frame_id"][-1])

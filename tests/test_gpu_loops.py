@@ -166,8 +166,18 @@ def test_errors_are_loud(matcher, pkg):
     with pytest.raises(pkg.LcmError) as e:
         matcher.detect_loops(1234)
     assert e.value.code == -6                                   # LCM_ERR_NOT_FOUND
-    with pytest.raises(pkg.LcmError):
-        matcher.query_scores(np.zeros((2049, 32), np.uint8), 100)
+    with pytest.raises(pkg.LcmError) as e:
+        matcher.query_scores(np.zeros((65536, 32), np.uint8), 100)     # a frame holds at most 65535 rows
+    assert e.value.code == -4                                   # LCM_ERR_CAPACITY
+    matcher.set_params(cross_check=1)                           # cross_check keeps the 2048-row limit on query frames
+    try:
+        with pytest.raises(pkg.LcmError) as e:
+            matcher.query_scores(np.zeros((2049, 32), np.uint8), 100)
+        assert e.value.code == -4
+    finally:
+        matcher.set_params(cross_check=0)
+    sc, _ = matcher.query_scores(np.zeros((2049, 32), np.uint8), 100)  # without it, 2049 rows are just a query frame
+    assert len(sc) == 1 and int(sc[0]["n_train"]) == 3
     matcher.clear()
 
 
@@ -275,9 +285,16 @@ def test_arena_grows_in_frames_and_rows(pkg, oracle):
         op = oracle.default_params(min_gap=1)
         for slot in (0, 3, 4, 60, len(frames) - 2, len(frames) - 1):
             assert scores[slot] == oracle.pair_score(q, frames[slot], op)
-        # frames wider than one workgroup's 2048 rows can be stored and matched against, but not used as a query
-        with pytest.raises(pkg.LcmError):
-            m.detect_loops(2 * (len(frames) - 2))
+        # a stored frame wider than one workgroup's 2048 rows as the QUERY: the packed bulk route serves it
+        cur = len(frames) - 2                                  # the 2500-row frame
+        sc2, _ = m.query_scores(frames[cur], 2 * cur)
+        for slot in (0, 3, 60, cur - 1):
+            assert sc2[slot] == oracle.pair_score(frames[cur], frames[slot], op)
+        m.set_params(min_matches=1, sim_threshold=0.0)
+        c_stored = m.detect_loops(2 * cur)
+        c_host = m.detect_loops(2 * cur, frames[cur])
+        np.testing.assert_array_equal(c_stored, c_host)
+        assert len(c_stored) == sum(1 for s in range(cur) if sizes[s] > 0)
 
 
 def test_fused_on_device_loop_test(matcher, oracle, pkg):
