@@ -25,6 +25,11 @@ LCM_API void lcs_destroy(lcs_system* s);
 /* processFrame (include/loop_closing.hpp:34) with the ORB stage already done: `desc` is what
  * detectFeatures would have put in Frame::descriptors (rows x 32, CV_8U), n_keypoints = keypoints.size(). */
 LCM_API int  lcs_process_frame(lcs_system* s, const uint8_t* desc, int rows, int n_keypoints, int frame_id);
+/* processFrames: the same for n frames in order, scored in micro-batches of up to 16 frames per launch (the online
+ * path's fast form; exact for any input: a launch only holds frames closer together than min_loop_gap).
+ * n_keypoints may be NULL (= rows). */
+LCM_API int  lcs_process_frames(lcs_system* s, const uint8_t* const* desc, const int* rows, const int* n_keypoints,
+                                const int* frame_ids, int n);
 /* matchFeatures(frame1, frame2) for two stored frames given by id (include/loop_closing.hpp:40). */
 LCM_API int  lcs_match_features(lcs_system* s, int frame1_id, int frame2_id, lcm_dmatch* out, int cap, int* n_out);
 /* detectLoops(current_frame_id) (include/loop_closing.hpp:48). */

@@ -631,6 +631,7 @@ _HOST_SIGNATURES = {
     "lcs_create": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "lcs_destroy": (None, [_vp]),
     "lcs_process_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "lcs_process_frames": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int]),
     "lcs_match_features": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _i32p]),
     "lcs_detect_loops": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i32p]),
     "lcs_get_consecutive_matches": (C.c_int, [_vp, _vp, C.c_int, _i32p]),
@@ -674,6 +675,16 @@ class LoopClosingSystem:
     def processFrame(self, descriptors, frame_id: int, num_keypoints: int = -1):
         d = _rows(descriptors)
         self._hcheck(self._lib.lcs_process_frame(self._s, _ptr(d), d.shape[0], num_keypoints, frame_id))
+
+    def processFrames(self, descriptor_list, frame_ids, num_keypoints=None):
+        """Several frames in order, scored in micro-batches (same result as processFrame for each)."""
+        ds = [_rows(d) for d in descriptor_list]
+        n = len(ds)
+        ptrs = (_vp * max(n, 1))(*[d.ctypes.data if d.shape[0] else None for d in ds])
+        rows = np.array([d.shape[0] for d in ds], np.int32)
+        ids = np.ascontiguousarray(frame_ids, np.int32)
+        kps = None if num_keypoints is None else np.ascontiguousarray(num_keypoints, np.int32)
+        self._hcheck(self._lib.lcs_process_frames(self._s, ptrs, _ptr(rows), _ptr(kps), _ptr(ids), n))
 
     def matchFeatures(self, frame1_id: int, frame2_id: int, cap: int = 65536) -> np.ndarray:
         out = np.zeros(cap, DMATCH_DTYPE)

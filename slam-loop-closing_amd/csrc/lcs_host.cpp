@@ -88,6 +88,107 @@ void LoopClosingSystem::processFrame(const uint8_t* descriptors, int rows, int n
     }
 }
 
+// frames_[first, first + count) are on the host list already, none of them in the device database yet: score them in
+// ONE launch per device against the database as it stands, apply the loop test, then store them.
+void LoopClosingSystem::processBatch(size_t first, size_t count, size_t& stored, std::vector<size_t>& closure_marks) {
+    stored = 0;
+    closure_marks.clear();
+    static const uint8_t dummy[32] = {0};
+    std::vector<const uint8_t*> q(count);
+    std::vector<int> nq(count), keys(count);
+    for (size_t k = 0; k < count; ++k) {
+        const Frame& f = frames_[first + k];
+        q[k] = f.rows() > 0 ? f.descriptors.data() : dummy;
+        nq[k] = f.rows();
+        keys[k] = keyOf(first + k);
+    }
+    const size_t n_db = (size_t)std::max(group_ ? lcm_group_db_size(group_) : lcm_db_size(matcher_), 0);
+    std::vector<lcm_score> sc(std::max<size_t>(n_db * count, 1));
+    std::vector<size_t> offs(count + 1, 0);
+    size_t n = 0;
+    if (group_) {
+        if (lcm_group_query_scores_batch(group_, q.data(), nq.data(), keys.data(), (int)count, sc.data(), sc.size(), &n, offs.data()) != LCM_OK)
+            raise("processFrames: lcm_group_query_scores_batch");
+    } else {
+        int ticket = -1;
+        if (lcm_query_submit_batch(matcher_, q.data(), nq.data(), keys.data(), (int)count, &ticket) != LCM_OK) raise("processFrames: lcm_query_submit_batch");
+        if (lcm_query_collect_batch(matcher_, ticket, sc.data(), sc.size(), &n, offs.data()) != LCM_OK) raise("processFrames: lcm_query_collect_batch");
+    }
+    // Record k of query b is its k-th eligible stored frame.  One device (or a group): that is position k.  One shard of
+    // a process-per-GPU run: the k-th frame THIS rank owns, position shard_rank + k * shard_world.
+    lcm_params p;
+    if (lcm_get_params(matcher_, &p) != LCM_OK) raise("processFrames: lcm_get_params");
+    for (size_t b = 0; b < count; ++b) {
+        const Frame& cur = frames_[first + b];
+        for (size_t k = offs[b]; k < offs[b + 1]; ++k) {
+            const size_t pos = group_ ? (k - offs[b]) : (size_t)shard_rank_ + (k - offs[b]) * (size_t)shard_world_;
+            const Frame& past = frames_[pos];
+            double sim = 0.0;
+            if (lcm_loop_test(&p, &sc[k], cur.num_keypoints, past.num_keypoints, &sim))
+                loop_closures_.push_back({cur.id, past.id, (int)sc[k].good_count, sim});
+        }
+        closure_marks.push_back(loop_closures_.size());        // closures recorded up to and including query b
+    }
+    for (size_t k = 0; k < count; ++k) {
+        const size_t pos = first + k;
+        const Frame& s = frames_[pos];
+        if (group_) {
+            if (lcm_group_append(group_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrames: lcm_group_append");
+        } else if (ownsPosition(pos)) {
+            if (lcm_db_append(matcher_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrames: lcm_db_append");
+        }
+        stored = k + 1;                                        // frame `pos` is in the device database (or another rank's)
+    }
+}
+
+void LoopClosingSystem::processFrames(const FrameInput* in, int n) {
+    if (n < 0 || (n > 0 && !in)) throw std::invalid_argument("processFrames: bad argument");
+    int last_id = frames_.empty() ? 0 : frames_.back().id;
+    for (int i = 0; i < n; ++i) {
+        if (in[i].rows < 0 || (in[i].rows > 0 && !in[i].descriptors)) throw std::invalid_argument("processFrames: bad descriptors");
+        if ((i > 0 || !frames_.empty()) && in[i].frame_id <= last_id) throw std::invalid_argument("processFrames: frame ids must increase");
+        last_id = in[i].frame_id;
+    }
+    const int span = std::max(min_loop_gap_, 1);            // frames of one launch must not be eligible for one another
+    int i = 0;
+    while (i < n) {
+        const size_t first = frames_.size();
+        const size_t closures_before = loop_closures_.size();
+        int cnt = 0;
+        // greedy cut: at most 16 frames, key(last) - key(first) < span
+        while (i + cnt < n && cnt < 16) {
+            const long long k0 = gap_by_position_ ? (long long)first : (long long)in[i].frame_id;
+            const long long kc = gap_by_position_ ? (long long)(first + (size_t)cnt) : (long long)in[i + cnt].frame_id;
+            if (cnt > 0 && kc - k0 >= span) break;
+            ++cnt;
+        }
+        for (int k = 0; k < cnt; ++k) {
+            Frame f;
+            f.id = in[i + k].frame_id;
+            f.num_keypoints = in[i + k].num_keypoints < 0 ? in[i + k].rows : in[i + k].num_keypoints;
+            f.descriptors.assign(in[i + k].descriptors, in[i + k].descriptors + (size_t)in[i + k].rows * 32);
+            frames_.push_back(std::move(f));
+        }
+        size_t stored = 0;
+        std::vector<size_t> marks;
+        try {
+            processBatch(first, (size_t)cnt, stored, marks);
+        } catch (...) {
+            // host list, loop list and device database must agree: keep the frames that were stored, with their closures
+            frames_.resize(first + stored);
+            loop_closures_.resize(stored == 0 || marks.size() < stored ? closures_before : marks[stored - 1]);
+            throw;
+        }
+        i += cnt;
+    }
+    // consecutive-frame matches of the LAST frame (README.md:96-97): what getConsecutiveMatches() would hold after
+    // frame-by-frame processing
+    if (n > 0) {
+        consecutive_matches_.clear();
+        if (frames_.size() >= 2) consecutive_matches_ = matchFeatures(frames_[frames_.size() - 2], frames_.back());
+    }
+}
+
 std::vector<DMatch> LoopClosingSystem::matchFeatures(const Frame& frame1, const Frame& frame2) {
     static_assert(sizeof(DMatch) == sizeof(lcm_dmatch), "DMatch layout");
     std::vector<DMatch> out((size_t)std::max(frame1.rows(), 1));
@@ -213,6 +314,15 @@ void lcs_destroy(lcs_system* s) { delete s; }
 int lcs_process_frame(lcs_system* s, const uint8_t* desc, int rows, int n_keypoints, int frame_id) {
     if (!s) return LCM_ERR_INVALID_ARG;
     return guarded([&] { s->sys.processFrame(desc, rows, n_keypoints, frame_id); });
+}
+
+int lcs_process_frames(lcs_system* s, const uint8_t* const* desc, const int* rows, const int* n_keypoints, const int* frame_ids, int n) {
+    if (!s || n < 0 || (n > 0 && (!desc || !rows || !frame_ids))) return LCM_ERR_INVALID_ARG;
+    return guarded([&] {
+        std::vector<loop_closing::LoopClosingSystem::FrameInput> in((size_t)n);
+        for (int i = 0; i < n; ++i) in[(size_t)i] = {desc[i], rows[i], n_keypoints ? n_keypoints[i] : -1, frame_ids[i]};
+        s->sys.processFrames(in.data(), n);
+    });
 }
 
 int lcs_match_features(lcs_system* s, int frame1_id, int frame2_id, lcm_dmatch* out, int cap, int* n_out) {

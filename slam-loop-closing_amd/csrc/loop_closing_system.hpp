@@ -63,6 +63,15 @@ public:
     // Process a single frame (hpp:34): store it, then check for loop closures (README.md:94-100).
     void processFrame(const uint8_t* descriptors, int rows, int num_keypoints, int frame_id);
 
+    // Several frames at once, same observable result as calling processFrame for each in order (frames, loop closures,
+    // the consecutive matches of the last frame), but scored as micro-batches: up to 16 frames per kernel launch
+    // (lcm_query_submit_batch), which is what keeps an MI355X busy when frames arrive faster than one launch per frame
+    // can serve them.  Frames of one launch are not compared with each other, so a launch only ever
+    // holds frames closer together than min_loop_gap (in ids, or in positions under setGapByPosition): the call cuts
+    // its input accordingly and is exact for any input.  Basic exception guarantee: frames that were stored stay.
+    struct FrameInput { const uint8_t* descriptors; int rows; int num_keypoints; int frame_id; };
+    void processFrames(const FrameInput* frames, int n);
+
     // Match features between two frames (hpp:40): BFMatcher(NORM_HAMMING).match + 2 x min-distance filter.
     std::vector<DMatch> matchFeatures(const Frame& frame1, const Frame& frame2);
 
@@ -111,6 +120,8 @@ private:
     int min_loop_gap_;                   // hpp:76
     int shard_rank_, shard_world_;
     bool gap_by_position_ = false;
+    // frames_[first, first + count): one micro-batch; `stored` / `closure_marks` report progress for the caller's rollback
+    void processBatch(size_t first, size_t count, size_t& stored, std::vector<size_t>& closure_marks);
     int keyOf(size_t position) const { return gap_by_position_ ? (int)position : frames_[position].id; }   // the matcher's id of a frame
 };
 

@@ -86,13 +86,18 @@ def test_header_default_threshold_and_errors(pkg, oracle):
         sys_.close()
 
 
-def test_sharded_host_objects_partition_the_candidates(pkg, oracle):
-    """Two LoopClosingSystem objects with shard_world = 2 on the one GPU: their candidates merge to the full set."""
+@pytest.mark.parametrize("batched", [False, True])
+def test_sharded_host_objects_partition_the_candidates(pkg, oracle, batched):
+    """Two LoopClosingSystem objects with shard_world = 2 on the one GPU: their candidates merge to the full set —
+    frame by frame, and through processFrames' micro-batches (record k of a shard = the k-th frame that shard owns)."""
     fs = pkg.synth.make_frames(30, 300, seed=5, dup_frac=0.3)
     gap = 4
     shards = [pkg.LoopClosingSystem(0.15, gap, 0, r, 2) for r in range(2)]
     try:
-        for f in range(fs.n_frames):
+        if batched:
+            for s in shards:
+                s.processFrames([fs.frame(f) for f in range(fs.n_frames)], [int(x) for x in fs.ids])
+        for f in range(0 if not batched else fs.n_frames, fs.n_frames):
             for s in shards:
                 s.processFrame(fs.frame(f), int(fs.ids[f]))
         p = oracle.default_params(min_gap=gap)
@@ -168,3 +173,38 @@ def test_gap_by_position_with_sparse_frame_ids(pkg, oracle):
             sys_.close()
     # by id: frame c sees ids <= 3c - 6 = positions <= c - 2; by position: positions <= c - 6 — a strict subset
     assert results[True] < results[False] and (60, 51, int(fs.counts[17])) in results[False] - results[True]
+
+
+@pytest.mark.parametrize("by_pos,id_step", [(False, 1), (False, 3), (True, 3)])
+def test_process_frames_in_micro_batches_equals_frame_by_frame(pkg, oracle, by_pos, id_step):
+    """processFrames (micro-batches of up to 16 frames per launch, cut so that no launch holds frames min_loop_gap apart)
+    leaves the same frames, loop closures and consecutive matches as processFrame called frame by frame — dense ids,
+    sparse ids (the id span forces smaller batches), and the positional gap reading."""
+    fs = pkg.synth.make_frames(70, 300, seed=9, ragged=True, dup_frac=0.3)
+    fs.rows[33] = fs.rows[20]; fs.counts[33] = fs.counts[20]
+    ids = (np.arange(fs.n_frames) * id_step).astype(np.int32)
+    gap, thr = 10, 0.05
+    one = pkg.LoopClosingSystem(thr, gap)
+    many = pkg.LoopClosingSystem(thr, gap)
+    try:
+        for s_ in (one, many):
+            if by_pos:
+                s_.setGapByPosition(True)
+        for f in range(fs.n_frames):
+            one.processFrame(fs.frame(f), int(ids[f]))
+        # uneven calls: 1 frame, 23 frames, an empty call, the rest
+        many.processFrames([fs.frame(0)], [int(ids[0])])
+        many.processFrames([fs.frame(f) for f in range(1, 24)], [int(ids[f]) for f in range(1, 24)])
+        many.processFrames([], [])
+        many.processFrames([fs.frame(f) for f in range(24, fs.n_frames)], [int(ids[f]) for f in range(24, fs.n_frames)])
+        assert many.numFrames() == one.numFrames() == fs.n_frames
+        a, b = one.getLoopClosures(), many.getLoopClosures()
+        assert len(a) > 0 and cand_tuples(a) == cand_tuples(b)       # (field by field: the record has 4 padding bytes)
+        np.testing.assert_array_equal(one.getConsecutiveMatches(), many.getConsecutiveMatches())
+        c = int(a["current_frame_id"][-1])
+        assert cand_tuples(one.detectLoops(c)) == cand_tuples(many.detectLoops(c))
+        with pytest.raises(pkg.capi.LcmError):
+            many.processFrames([fs.frame(3)], [int(ids[3])])          # ids must increase
+        assert many.numFrames() == fs.n_frames
+    finally:
+        one.close(); many.close()
