@@ -81,8 +81,4 @@ int cross_score_prefixes(lcm_handle* h, const uint8_t* d_qbase, const uint32_t* 
     return LCM_OK;
 }
 
-// OPT-IN variant 4: the bulk search on the matrix cores (lcm_mfma.hip).  Same records as variants 0 / 1, bit for bit.
-// qbase / q_pitch_rows / q_frame_of describe the query set's packed rows (the arena itself in self mode); nqv[c] and
-// offsets come from the plan.  Work goes out in chunks of <= 524,288 pairs (4 GiB of per-row distances).
-
 }  // namespace lcm
