@@ -151,21 +151,22 @@ def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi,
     er = pkg.sharding.shard_eligible_counts(fs.ids, args.gap, rank, world)
     cap = int(er.max()) * B if len(er) else 1
 
+    depth = max(1, min(args.stream_depth, 4))                   # batches in flight (the library has 4 query slots)
+
     def one_pass():
         m.clear()
         out = []
-        prev = None
+        pending = []
         for f0 in range(0, n_frames, B):
             fr = range(f0, min(f0 + B, n_frames))
-            t = m.query_submit_batch([frames[f] for f in fr], [ids[f] for f in fr])   # enqueued; the host moves on
+            pending.append(m.query_submit_batch([frames[f] for f in fr], [ids[f] for f in fr]))   # enqueued; the host moves on
             for f in fr:
                 if f % world == rank:
                     m.append(ids[f], frames[f])                 # copy stream: overlaps the launch just submitted
-            if prev is not None:
-                out.append(m.query_collect_batch(prev, cap)[0])  # results of the PREVIOUS batch
-            prev = t
-        if prev is not None:
-            out.append(m.query_collect_batch(prev, cap)[0])
+            if len(pending) == depth:
+                out.append(m.query_collect_batch(pending.pop(0), cap)[0])  # results of the OLDEST batch in flight
+        for t in pending:
+            out.append(m.query_collect_batch(t, cap)[0])
         m.sync()
         return np.concatenate(out) if out else np.zeros(0, pkg.capi.SCORE_DTYPE)
 
@@ -216,7 +217,7 @@ def stream_mode(args, pkg, torch, dist, fs, world, rank, local_rank, dev, multi,
             "config": {"workload": "STREAMING (online append + micro-batched queries, host rows over PCIe): " + wl_desc,
                        "frames": n_frames, "descriptors_per_frame": fs.stride_rows, "min_gap": args.gap,
                        "pairs_per_step": total_pairs, "distances_per_step": total_dist, "seed": seed,
-                       "stream_batch": B, "sharding": "cyclic by frame" if world > 1 else "none",
+                       "stream_batch": B, "batches_in_flight": depth, "sharding": "cyclic by frame" if world > 1 else "none",
                        "kernel_variant": args.variant if args.variant in (4, 5) else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -313,6 +314,7 @@ def main():
     ap.add_argument("--mode", default="batch", help="batch (default: one all-vs-all pass per step) | stream (online: "
                     "per frame, score it against the database, then append it — BASELINE.json configs[4] shape)")
     ap.add_argument("--stream-batch", type=int, default=8, help="--mode stream: frames per micro-batch (1..16; 1 = frame by frame)")
+    ap.add_argument("--stream-depth", type=int, default=2, help="--mode stream: micro-batches in flight before the oldest is collected (1..4)")
     ap.add_argument("--online-streams", type=int, default=1, help="--mode stream: 1 = one stream per query slot (default), 0 = the handle's stream only")
     ap.add_argument("--online-split", type=int, default=-1, help="--mode stream: query rows per lane of the split mode (1, 2, 4), 0 = never split, -1 = automatic")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra blocks of the default N = 1 line (cfg4 fused step)")
