@@ -328,7 +328,8 @@ LCM_API int  lcm_merge_shard_scores_device(lcm_handle* h, const void* d_gathered
 
 /* Measurement knobs (defaults are the measured optima; results never depend on them):
  *   LCM_TUNE_ITEM_SLOTS   stored frames per work item of the bulk search, 1..64; 0 = automatic
- *   LCM_TUNE_ONLINE_SPLIT query rows per lane of the online split mode: 1, 2, 4; 0 = never split; -1 = automatic
+ *   LCM_TUNE_ONLINE_SPLIT query rows per lane of the online split mode: 1, 2, 4 (256-thread workgroups), 16 / 32 (64- /
+ *                         128-thread workgroups of 8 rows per lane); 0 = never split; -1 = automatic
  *   LCM_TUNE_PACKED       bulk search with the query rows of consecutive frames packed into full 2048-row workgroups:
  *                         1 = always, 0 = never, -1 = automatic (when packing saves lane slots), 2 = always, with
  *                         1536-row workgroups (6 rows per lane at 8 waves per SIMD: an A/B, within 0.5 % of 1)

@@ -281,8 +281,8 @@ int lcm_set_tuning(lcm_handle* h, int knob, int value) {
             if (value < 0 || value > 64) return fail(LCM_ERR_INVALID_ARG, "item slots must be 0 (automatic) .. 64");
             h->tune_item_slots = value; h->plan.key = 0; return LCM_OK;
         case LCM_TUNE_ONLINE_SPLIT:
-            if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4)
-                return fail(LCM_ERR_INVALID_ARG, "online split must be -1 (automatic), 0 (off), 1, 2 or 4 rows per lane");
+            if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 16 && value != 32)
+                return fail(LCM_ERR_INVALID_ARG, "online split must be -1 (automatic), 0 (off), 1, 2, 4 (rows per lane of a 256-thread workgroup), 16 or 32 (64 / 128 threads x 8 rows)");
             h->tune_online_split = value; return LCM_OK;
         case LCM_TUNE_ONLINE_STREAMS:
             if (value != 0 && value != 1) return fail(LCM_ERR_INVALID_ARG, "online streams must be 0 (the handle's stream) or 1 (one per query slot)");

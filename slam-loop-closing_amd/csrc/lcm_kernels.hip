@@ -657,6 +657,8 @@ hipError_t launch_score_split(const ScoreArgs& a, uint32_t n_items, int qpt, hip
         case 4: return launch_rowlane<256, 4>(a, n_items, true, false, st);
         case 2: return launch_rowlane<256, 2>(a, n_items, true, false, st);
         case 1: return launch_rowlane<256, 1>(a, n_items, true, false, st);
+        case 16: return launch_rowlane<64, 8>(a, n_items, true, false, st);       // 512-row chunks, one wave per workgroup
+        case 32: return launch_rowlane<128, 8>(a, n_items, true, false, st);      // 1024-row chunks, two waves
         default: return hipErrorInvalidValue;
     }
 }

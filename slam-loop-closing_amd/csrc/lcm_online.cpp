@@ -2,6 +2,12 @@
 // Part of liblcm_hip.so's host side (C ABI in include/lcm.h); shared state and helpers: lcm_internal.h.
 #include "lcm_internal.h"
 
+// Split-mode codes (LCM_TUNE_ONLINE_SPLIT): 1 / 2 / 4 = 256-thread workgroups holding that many query rows per lane
+// (256- / 512- / 1024-row chunks); 16 / 32 = 64- / 128-thread workgroups of 8 rows per lane (512- / 1024-row chunks: the
+// bulk kernel's per-wave shape at a finer workgroup grain).
+static inline bool is_split(int qpt) { return qpt == 1 || qpt == 2 || qpt == 4 || qpt == 16 || qpt == 32; }
+static inline int split_chunk_rows(int qpt) { return qpt == 16 ? 512 : qpt == 32 ? 1024 : 256 * qpt; }
+
 extern "C" {
 
 // scores of (query frame at q_rows[q_frame]) against stored slots [0, n_elig)
@@ -56,8 +62,8 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
     a.imp_nq = nq; a.imp_total = (uint32_t)n_elig;
     HIP_TRY(hipEventRecord(h->ev_start, S));
     HIP_TRY(hipEventRecord(q.k0, S));
-    if (qpt == 1 || qpt == 2 || qpt == 4) {
-        const int chunk_rows = 256 * qpt;
+    if (is_split(qpt)) {
+        const int chunk_rows = split_chunk_rows(qpt);
         const int n_chunks = (nq + chunk_rows - 1) / chunk_rows;
         const size_t n_items = (size_t)n_elig * n_chunks;
         rc = ensure_dev(q.d_dist, q.d_dist_n, n_items * chunk_rows); if (rc) return rc;
@@ -135,8 +141,8 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
     a.db_rows = (const uint32_t*)h->d_rows; a.db_counts = h->d_counts; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
     a.imp_nbatch = (uint32_t)B;
-    const bool split = (qpt == 1 || qpt == 2 || qpt == 4);
-    const int chunk_rows = split ? 256 * qpt : rows_per_query;
+    const bool split = is_split(qpt);
+    const int chunk_rows = split ? split_chunk_rows(qpt) : rows_per_query;
     const int n_chunks = split ? (max_nq + chunk_rows - 1) / chunk_rows : 1;
     if (rows_per_query % chunk_rows != 0 || n_chunks * chunk_rows > rows_per_query)
         return fail(LCM_ERR_INVALID_ARG, "batch staging pitch %d does not fit %d chunks of %d rows", rows_per_query, n_chunks, chunk_rows);
@@ -375,7 +381,7 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
             else if (total < 6144) qpt = 2;
             else if (total < lcm::ONLINE_SPLIT_MAX_PAIRS) qpt = 4;
         }
-        if (qpt == 1 || qpt == 2 || qpt == 4) pitch = round_up(max_nq, 256 * qpt);
+        if (is_split(qpt)) pitch = round_up(max_nq, split_chunk_rows(qpt));
     }
     if (h->params.cross_check) pitch = padded_rows(std::max(max_nq, 1)) + 2 * ROW_PAD;   // room for every query's padding rows
     const size_t bytes = (size_t)pitch * (size_t)n_queries * LCM_DESC_BYTES;
