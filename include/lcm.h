@@ -290,6 +290,10 @@ typedef struct lcm_group_info {
 } lcm_group_info;
 /* device_ids == NULL: devices 0 .. n_devices-1.  n_devices <= 8. */
 LCM_API int  lcm_group_create(const lcm_params* params, int n_devices, const int* device_ids, lcm_group** out);
+/* Rehearsal form for boxes with ONE GPU: n_shards matchers on device_id, the two exchange steps as device-local copies
+ * instead of RCCL calls.  Same results as any other group; exists so that the multi-device index arithmetic (cyclic
+ * ownership, rank-major query buffer, gatherv offsets, device merge) is exercised for W > 1 where no second GPU is. */
+LCM_API int  lcm_group_create_loopback(const lcm_params* params, int n_shards, int device_id, lcm_group** out);
 LCM_API void lcm_group_destroy(lcm_group* g);
 LCM_API int  lcm_group_size(const lcm_group* g);                    /* W */
 LCM_API int  lcm_group_db_size(const lcm_group* g);                 /* frames over all shards */

@@ -126,6 +126,7 @@ _SIGNATURES = {
     "lcm_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
     "lcm_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "lcm_group_create": (C.c_int, [C.POINTER(Params), C.c_int, _i32p, C.POINTER(_vp)]),
+    "lcm_group_create_loopback": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.POINTER(_vp)]),
     "lcm_group_destroy": (None, [_vp]),
     "lcm_group_size": (C.c_int, [_vp]),
     "lcm_group_db_size": (C.c_int, [_vp]),
@@ -530,10 +531,15 @@ def merge_shard_scores_host(shard_scores: Sequence[np.ndarray], ids, min_gap: in
 class Group:
     """lcm_group: one process, W devices, stored frames sharded cyclically by arrival position, RCCL inside."""
 
-    def __init__(self, params: Optional[Params] = None, n_devices: int = 1, device_ids: Optional[Sequence[int]] = None):
+    def __init__(self, params: Optional[Params] = None, n_devices: int = 1, device_ids: Optional[Sequence[int]] = None,
+                 loopback_device: Optional[int] = None):
+        """loopback_device: rehearsal form — n_devices shards on that ONE device, exchange steps as device-local copies."""
         self._lib = load_library()
         self._g = _vp()
         p = params if params is not None else default_params()
+        if loopback_device is not None:
+            _check(self._lib.lcm_group_create_loopback(C.byref(p), n_devices, loopback_device, C.byref(self._g)))
+            return
         ids = None if device_ids is None else np.ascontiguousarray(device_ids, np.int32)
         _check(self._lib.lcm_group_create(C.byref(p), n_devices, None if ids is None else ids.ctypes.data_as(_i32p),
                                           C.byref(self._g)))

@@ -39,6 +39,10 @@ struct GFrame { int32_t id, n, n_kp; };
 
 struct lcm_group {
     int world = 0;
+    // Rehearsal form (lcm_group_create_loopback): the W shards are W matchers on ONE device and the two exchange steps
+    // are device-local copies instead of RCCL calls — every index computation of the multi-device path (cyclic
+    // ownership, rank-major query buffer, gatherv offsets, merge) runs for W > 1 on a box with a single GPU.
+    bool loopback = false;
     lcm_params params{};
     std::vector<int> devices;
     std::vector<lcm_handle*> h;
@@ -187,7 +191,7 @@ int lcm_merge_shard_scores(const lcm_score* const* shard_scores, const size_t* s
     });
 }
 
-int lcm_group_create(const lcm_params* params, int n_devices, const int* device_ids, lcm_group** out) {
+static int group_create(const lcm_params* params, int n_devices, const int* device_ids, bool loopback, int loop_device, lcm_group** out) {
     if (!out) return fail(LCM_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (n_devices < 1 || n_devices > MAX_WORLD) return fail(LCM_ERR_INVALID_ARG, "n_devices must be 1..%d", MAX_WORLD);
@@ -200,12 +204,13 @@ int lcm_group_create(const lcm_params* params, int n_devices, const int* device_
         lcm_group* g = new lcm_group();
         auto bail = [&](int rc) { const std::string why = lcm::last_error(); lcm_group_destroy(g); lcm::last_error() = why; return rc; };
         g->world = n_devices;
+        g->loopback = loopback;
         lcm_params_default(&g->params);
         if (params) g->params = *params;
         for (int r = 0; r < n_devices; ++r) {
-            const int dev = device_ids ? device_ids[r] : r;
+            const int dev = loopback ? loop_device : (device_ids ? device_ids[r] : r);
             if (dev < 0 || dev >= have) return bail(fail(LCM_ERR_INVALID_ARG, "device id %d out of range [0,%d)", dev, have));
-            for (int d : g->devices) if (d == dev) return bail(fail(LCM_ERR_INVALID_ARG, "device id %d listed twice", dev));
+            if (!loopback) for (int d : g->devices) if (d == dev) return bail(fail(LCM_ERR_INVALID_ARG, "device id %d listed twice", dev));
             g->devices.push_back(dev);
         }
         const size_t W = (size_t)n_devices;
@@ -217,15 +222,25 @@ int lcm_group_create(const lcm_params* params, int n_devices, const int* device_
             const int rc = lcm_create(&g->params, g->devices[(size_t)r], nullptr, &g->h[(size_t)r]);
             if (rc) return bail(rc);
         }
-        g->comms.assign(W, nullptr);
-        ncclResult_t nr = ncclCommInitAll(g->comms.data(), n_devices, g->devices.data());
-        if (nr != ncclSuccess) { g->comms.clear(); return bail(fail(LCM_ERR_HIP, "ncclCommInitAll failed: %s", ncclGetErrorString(nr))); }
+        if (!loopback) {
+            g->comms.assign(W, nullptr);
+            ncclResult_t nr = ncclCommInitAll(g->comms.data(), n_devices, g->devices.data());
+            if (nr != ncclSuccess) { g->comms.clear(); return bail(fail(LCM_ERR_HIP, "ncclCommInitAll failed: %s", ncclGetErrorString(nr))); }
+        }
         if (hipSetDevice(g->devices[0]) != hipSuccess || hipEventCreate(&g->ev0) != hipSuccess ||
             hipEventCreate(&g->ev1) != hipSuccess || hipEventCreate(&g->ev2) != hipSuccess)
             return bail(fail(LCM_ERR_HIP, "hipEventCreate failed"));
         *out = g;
         return LCM_OK;
     });
+}
+
+int lcm_group_create(const lcm_params* params, int n_devices, const int* device_ids, lcm_group** out) {
+    return group_create(params, n_devices, device_ids, false, 0, out);
+}
+
+int lcm_group_create_loopback(const lcm_params* params, int n_shards, int device_id, lcm_group** out) {
+    return group_create(params, n_shards, nullptr, true, device_id, out);
 }
 
 void lcm_group_destroy(lcm_group* g) {
@@ -327,13 +342,22 @@ int lcm_group_all_vs_all(lcm_group* g, lcm_score* out_scores, size_t cap, size_t
             rc = ensure_dev(g->d_qrows[(size_t)r], g->d_qrows_bytes[(size_t)r], shard_bytes * (size_t)W, 512); if (rc) return rc;
             rc = ensure_dev(g->d_qcounts[(size_t)r], g->d_qcounts_n[(size_t)r], (size_t)shard_cap * (size_t)W); if (rc) return rc;
         }
-        NCCL_TRY(ncclGroupStart());
-        for (int r = 0; r < W; ++r) {
-            lcm_handle* h = g->h[(size_t)r];
-            NCCL_TRY(ncclAllGather(h->d_rows, g->d_qrows[(size_t)r], shard_bytes, ncclUint8, g->comms[(size_t)r], h->stream));
-            NCCL_TRY(ncclAllGather(h->d_counts, g->d_qcounts[(size_t)r], (size_t)shard_cap, ncclInt32, g->comms[(size_t)r], h->stream));
+        if (g->loopback) {
+            // what ncclAllGather delivers, as device-local copies (every shard was synchronised above)
+            for (int r = 0; r < W; ++r)
+                for (int s = 0; s < W; ++s) {
+                    HIP_TRY(hipMemcpyAsync(g->d_qrows[(size_t)r] + (size_t)s * shard_bytes, g->h[(size_t)s]->d_rows, shard_bytes, hipMemcpyDeviceToDevice, g->h[(size_t)r]->stream));
+                    HIP_TRY(hipMemcpyAsync(g->d_qcounts[(size_t)r] + (size_t)s * (size_t)shard_cap, g->h[(size_t)s]->d_counts, sizeof(int32_t) * (size_t)shard_cap, hipMemcpyDeviceToDevice, g->h[(size_t)r]->stream));
+                }
+        } else {
+            NCCL_TRY(ncclGroupStart());
+            for (int r = 0; r < W; ++r) {
+                lcm_handle* h = g->h[(size_t)r];
+                NCCL_TRY(ncclAllGather(h->d_rows, g->d_qrows[(size_t)r], shard_bytes, ncclUint8, g->comms[(size_t)r], h->stream));
+                NCCL_TRY(ncclAllGather(h->d_counts, g->d_qcounts[(size_t)r], (size_t)shard_cap, ncclInt32, g->comms[(size_t)r], h->stream));
+            }
+            NCCL_TRY(ncclGroupEnd());
         }
-        NCCL_TRY(ncclGroupEnd());
         g->info.gathered_query_bytes = (uint64_t)shard_bytes * (uint64_t)W;
 
         // ---- 2. per-shard search: one host thread per device plans + launches on that device's stream
@@ -381,7 +405,15 @@ int lcm_group_all_vs_all(lcm_group* g, lcm_score* out_scores, size_t cap, size_t
         HIP_TRY(hipEventRecord(g->ev0, g->h[0]->stream));
         std::vector<uint32_t> shard_base((size_t)W + 1, 0);
         for (int r = 0; r < W; ++r) shard_base[(size_t)r + 1] = shard_base[(size_t)r] + offr[(size_t)r][(size_t)N];
-        if (W > 1) {
+        if (W > 1 && g->loopback) {
+            // what the grouped ncclSend / ncclRecv delivers: each shard's records behind device 0's
+            for (int r = 1; r < W; ++r) {
+                const size_t bytes = (size_t)offr[(size_t)r][(size_t)N] * sizeof(lcm_score);
+                if (!bytes) continue;
+                rc = lcm_sync(g->h[(size_t)r]); if (rc) return rc;
+                HIP_TRY(hipMemcpyAsync(g->d_gather + shard_base[(size_t)r], g->d_scores[(size_t)r], bytes, hipMemcpyDeviceToDevice, g->h[0]->stream));
+            }
+        } else if (W > 1) {
             NCCL_TRY(ncclGroupStart());
             for (int r = 1; r < W; ++r) {
                 const size_t bytes = (size_t)offr[(size_t)r][(size_t)N] * sizeof(lcm_score);

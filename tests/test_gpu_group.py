@@ -154,3 +154,61 @@ def test_group_honours_cross_check_and_kernel_variants(pkg, oracle, mode):
         pq = [20] * fs.n_frames
         wq, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, pq, list(range(fs.n_frames)), op, n_threads=8)
         np.testing.assert_array_equal(sc, wq)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_loopback_group_of_w_shards_equals_single_handle(pkg, oracle, world):
+    """lcm_group_create_loopback: W shards on the ONE device, exchange steps as device-local copies.  Everything the
+    multi-device path computes for W > 1 runs here on real kernels — cyclic ownership, shard arenas of equal geometry,
+    the rank-major gathered query buffer and its q_frame_of addressing, W host threads planning and launching, the
+    gatherv offsets, k_merge_shards — and must give the single handle's bytes (== oracle).  Only RCCL's transport is not
+    in it.  Also the online group calls, the packed bulk route per shard (2000-row frames), and an uneven shard split."""
+    n_frames = 8 * 23 + 5                                         # not a multiple of any world size used
+    fs = pkg.synth.make_frames(n_frames, 2000, seed=70 + world, ragged=True, dup_frac=0.3)
+    fs.counts[7] = 0
+    fs.counts[11] = 1
+    p = pkg.default_params()
+    p.min_gap = 3
+    with pkg.Group(p, n_devices=world, loopback_device=0) as g, pkg.Matcher(p) as m:
+        assert g.world == world
+        g.reserve(n_frames, 2000)
+        for f in range(n_frames):
+            g.append(int(fs.ids[f]), fs.frame(f))
+            m.append(int(fs.ids[f]), fs.frame(f))
+        merged, offs = g.all_vs_all()
+        n, moffs = m.all_vs_all_plan()
+        d = m.dev_alloc(n * 8)
+        m.all_vs_all(d, n)
+        single = np.zeros(n, pkg.capi.SCORE_DTYPE)
+        m.sync(); m.dev_download(d, single); m.dev_free(d)
+        np.testing.assert_array_equal(offs, moffs)
+        np.testing.assert_array_equal(merged, single)
+        rng = np.random.default_rng(world)
+        pq, pt = [], []
+        for _ in range(160):
+            c = int(rng.integers(3, n_frames)); t = int(rng.integers(0, c - 2))
+            pq.append(c); pt.append(t)
+        want, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, pq, pt, oracle.default_params(min_gap=3), n_threads=8)
+        np.testing.assert_array_equal(merged[offs[pq].astype(np.int64) + np.array(pt)], want)
+        gi = g.info()
+        assert gi.n_devices == world and gi.pairs == n and gi.gathered_score_bytes == (n - sum(1 for c in range(n_frames) for t in range(max(c - 2, 0)) if t % world == 0)) * 8
+        # a second search (cached plans on every shard), then more frames
+        again, _ = g.all_vs_all()
+        np.testing.assert_array_equal(again, single)
+        # online through the group: single query, micro-batch, detectLoops
+        q = fs.frame(20)
+        sc, ids = g.query_scores(q, int(fs.ids[-1]) + 3)
+        s1, ids1 = m.query_scores(q, int(fs.ids[-1]) + 3)
+        np.testing.assert_array_equal(sc, s1)
+        np.testing.assert_array_equal(ids, ids1)
+        qb = [fs.frame(5), fs.frame(7), fs.frame(40)]
+        qids = [int(fs.ids[-1]) + 3, int(fs.ids[-1]) + 4, 60]    # the last one sees only a prefix of the database
+        bs, boffs = g.query_scores_batch(qb, qids)
+        t = m.query_submit_batch(qb, qids)
+        ms, mo = m.query_collect_batch(t)
+        np.testing.assert_array_equal(boffs, mo)
+        np.testing.assert_array_equal(bs, ms)
+        c1 = g.detect_loops(int(fs.ids[-1]) + 3, q)
+        c2 = m.detect_loops(int(fs.ids[-1]) + 3, q)
+        np.testing.assert_array_equal(c1["matched_frame_id"], c2["matched_frame_id"])
+        np.testing.assert_array_equal(c1["num_matches"], c2["num_matches"])
