@@ -273,6 +273,28 @@ def cfg4_fused_extra(pkg, torch, dev, local_rank, gap):
     return out
 
 
+def group_loopback_extra(pkg, fs, gap, expect, world=8):
+    """cfg2 through the multi-device path's own code for W = 8 on this ONE GPU (lcm_group_create_loopback: 8 shards as 8
+    matchers on the device, exchange steps as device-local copies): rank-major query buffer, 8 planning threads, 8
+    concurrent shard searches, gatherv offsets, device merge.  The merged bytes must equal the single handle's."""
+    p = pkg.default_params()
+    p.min_gap = gap
+    with pkg.Group(p, n_devices=world, loopback_device=0) as g:
+        g.reserve(fs.n_frames, fs.stride_rows)
+        for f in range(fs.n_frames):
+            g.append(int(fs.ids[f]), fs.frame(f))
+        g.all_vs_all()
+        t0 = time.perf_counter()
+        merged, _ = g.all_vs_all()
+        t1 = time.perf_counter()
+        gi = g.info()
+    return {"api": "lcm_group_create_loopback + lcm_group_all_vs_all", "shards_on_this_gpu": world, "ms": (t1 - t0) * 1e3,
+            "pairs": int(gi.pairs), "value": int(gi.distances) / (t1 - t0), "unit": "distances/s",
+            "equals_single_handle_result": bool(expect is not None and len(merged) == len(expect) and np.array_equal(merged, expect)),
+            "note": "rehearsal of the W = 8 index arithmetic on one device, RCCL's transport replaced by device-local copies; "
+                    "not a scaling measurement"}
+
+
 def group_extra(pkg, fs, gap, expect):
     """The same cfg2 search through lcm_group_* (the multi-GPU entry of the C ABI) with the devices this process can
     see used as ONE group of size 1: ncclCommInitAll, all-gather of the shard arena into the query buffer, search,
@@ -650,6 +672,7 @@ def main():
             del scores, d_rows
             torch.cuda.empty_cache()
             out["extra"] = {"group_of_one": group_extra(pkg, fs, args.gap, single),
+                            "group_loopback_8": group_loopback_extra(pkg, fs, args.gap, single),
                             "cfg4_fused": cfg4_fused_extra(pkg, torch, dev, local_rank, args.gap)}
         emit(out)
     m.close()
