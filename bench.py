@@ -628,7 +628,7 @@ def main():
                          "fold_kernel_ms": float(np.mean(fold_ms)) if fold_ms else None,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "note": "this path is VALU-bound by ~200x (0.016 algorithmic bytes per distance); see roofline_valu. "
-                                 "traffic = L2-to-fabric bytes incl. Infinity-Cache hits; the argmin kernel's re-scan re-reads 16 "
+                                 "traffic = L2-to-fabric bytes incl. Infinity-Cache hits; the argmin kernel's re-scan re-reads 8 "
                                  "of ~2000 rows per (query row, pair) and ~1/3 of those miss the XCD's L2; the packed route adds "
                                  "4 bytes written + read per (pair, query row) of scratch (8 KB per pair, < 1 % of HBM peak)"},
             "roofline_valu": {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
@@ -642,7 +642,7 @@ def main():
                 "what": ("same workload through lcm_all_vs_all, kernel variant 0: best distance per query row only (what a "
                          "LoopCandidate needs; no train index)" if argmin_api else
                          "same workload through lcm_all_vs_all_argmin: per-query min AND first-minimum train index "
-                         "(16-row group keys in lane-private LDS + re-scan), per-pair index checksum written"),
+                         "(8-row group keys in lane-private LDS + re-scan), per-pair index checksum written"),
                 "kernel_ms": other_ms, "distances_per_s": local_dist / (other_ms * 1e-3)},
             "cpu_baseline": cpu,
         }

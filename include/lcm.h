@@ -261,7 +261,7 @@ LCM_API int  lcm_last_bulk_scores(const lcm_handle* h, const void** d_scores, si
 
 /* Select the kernel variant of the bulk / online scoring (A/B measurement; results are identical):
  * 0 = query-row-per-lane, best distance per query row; 1 = same + the first train row attaining it (argmin, by
- * 16-row group keys and a re-scan of the winning group); 2 / 3 = the train-row-per-lane mapping with LDS-staged
+ * 8-row group keys and a re-scan of the winning group); 2 / 3 = the train-row-per-lane mapping with LDS-staged
  * queries and wavefront shuffle reductions, distances only / (dist, idx) keys.
  * 4 = OPT-IN, NOT the product path: BASELINE.json's north_star rules the matrix cores out ("no MFMA"); this variant
  * runs the search on v_mfma_i32_32x32x32_i8 over a +1 / -1 int8 image of

@@ -101,33 +101,24 @@ __device__ __forceinline__ void fold2_min(uint32_t& best, const uint32_t (&q)[8]
 }
 
 // Re-scan step (ARGMIN kernels): the distance between this lane's query row and ONE train row that the lane picks
-// itself (byte offset `off` from the wave-uniform frame base).  Hand-written so that it needs exactly 5 temporary
-// VGPRs: the 64 registers holding the query rows stay where they are (the compiler's own version of this loop wants
-// 157 VGPRs and spills the query rows of the main loop).
+// itself (byte offset `off` from the wave-uniform frame base).  The two loads and their wait are one asm statement
+// (8 temporary VGPRs, nothing for the compiler to hoist or interleave across rows: its own version of this loop wanted
+// 157 VGPRs and spilled the query rows of the main loop); the 8 xor / popcount-accumulate pairs are plain C++.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t rescan_distance(const uint32_t (&q)[8], const uint32_t* base, uint32_t off) {
-    uint32_t d, t0, t1, t2, t3;
+    // the whole 32-byte row in ONE round trip (two 16-byte loads, one wait): the re-scan is a chain of dependent loads,
+    // and with short stored frames (a few hundred rows) its latency — not its arithmetic — is what the argmin costs
+    u32x4 lo, hi;
     asm volatile(
-        "global_load_dword %1, %5, %6\n\t"
-        "global_load_dword %2, %5, %6 offset:4\n\t"
-        "global_load_dword %3, %5, %6 offset:8\n\t"
-        "global_load_dword %4, %5, %6 offset:12\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_xor_b32_e32 %1, %7, %1\n\tv_bcnt_u32_b32 %0, %1, 0\n\t"
-        "v_xor_b32_e32 %2, %8, %2\n\tv_bcnt_u32_b32 %0, %2, %0\n\t"
-        "v_xor_b32_e32 %3, %9, %3\n\tv_bcnt_u32_b32 %0, %3, %0\n\t"
-        "v_xor_b32_e32 %4, %10, %4\n\tv_bcnt_u32_b32 %0, %4, %0\n\t"
-        "global_load_dword %1, %5, %6 offset:16\n\t"
-        "global_load_dword %2, %5, %6 offset:20\n\t"
-        "global_load_dword %3, %5, %6 offset:24\n\t"
-        "global_load_dword %4, %5, %6 offset:28\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_xor_b32_e32 %1, %11, %1\n\tv_bcnt_u32_b32 %0, %1, %0\n\t"
-        "v_xor_b32_e32 %2, %12, %2\n\tv_bcnt_u32_b32 %0, %2, %0\n\t"
-        "v_xor_b32_e32 %3, %13, %3\n\tv_bcnt_u32_b32 %0, %3, %0\n\t"
-        "v_xor_b32_e32 %4, %14, %4\n\tv_bcnt_u32_b32 %0, %4, %0"
-        : "=&v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(off), "s"(base), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7])
+        "global_load_dwordx4 %0, %2, %3\n\t"
+        "global_load_dwordx4 %1, %2, %3 offset:16\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(off), "s"(base)
         : "memory");
+    uint32_t d = __popc(q[0] ^ lo.x);
+    d += __popc(q[1] ^ lo.y); d += __popc(q[2] ^ lo.z); d += __popc(q[3] ^ lo.w);
+    d += __popc(q[4] ^ hi.x); d += __popc(q[5] ^ hi.y); d += __popc(q[6] ^ hi.z); d += __popc(q[7] ^ hi.w);
     return d;
 }
 
@@ -137,18 +128,20 @@ __device__ __forceinline__ uint32_t rescan_distance(const uint32_t (&q)[8], cons
 //
 //   * the inner loop is the distance-only one in both cases (fold2_min: 16 x (v_xor, s_nop, v_bcnt) + v_min3 per
 //     two train rows) — no index arithmetic per distance;
-//   * every ARGMIN_GROUP (16) train rows, each lane folds `running_min << 22 | group` into a PRIVATE LDS word per
-//     query row with ds_min_u32 (1 v_lshl_or_b32 + 1 LDS atomic per 16 distances; the LDS instruction does not
+//   * every ARGMIN_GROUP (8) train rows, each lane folds `running_min << 22 | group` into a PRIVATE LDS word per
+//     query row with ds_min_u32 (1 v_lshl_or_b32 + 1 LDS atomic per 8 distances; the LDS instruction does not
 //     hold the VALU).  The running minimum never rises, so the word ends up holding (best distance, FIRST group in
 //     which the running minimum reached it);
-//   * after the scan, the lane re-reads just that group's 16 rows (per-lane global loads, L2-resident: the frame
+//   * after the scan, the lane re-reads just that group's 8 rows (per-lane global loads, L2-resident: the frame
 //     was streamed a moment ago) and takes min(dist << 22 | row): the first row of the first group with the best
-//     distance = the first minimum.  16 of ~2000 rows = 0.8 % extra distances.
+//     distance = the first minimum.  8 of ~2000 rows = 0.4 % extra distances; each row is ONE
+//     round trip (two 16-byte loads), because with short stored frames the chain of dependent loads, not the
+//     arithmetic, is what the argmin costs (256-row frames: +100 % with 2 round trips x 16 rows, +6 % now).
 //
 // The words are lane-private (index j * THREADS + tid): LDS serves as 8 extra registers with a free min-ALU, no
 // barrier is involved.
 // ---------------------------------------------------------------------------------------------------
-constexpr int ARGMIN_GROUP = 16;      // train rows per (dist, group) key; a multiple of the 4 rows of one loop trip
+constexpr int ARGMIN_GROUP = 8;       // train rows per (dist, group) key; a multiple of the 4 rows of one loop trip
 
 // ARGMIN_MODE: 0 = distances only; 1 = argmin by group keys + re-scan (bulk: throughput, the re-scan's dependent loads
 // hide behind the other waves); 2 = argmin by a packed key per distance (v_lshl_or_b32 per distance, +8 % VALU, no
@@ -163,7 +156,10 @@ constexpr int ARGMIN_GROUP = 16;      // train rows per (dist, group) key; a mul
 // (best distance, or best key in the argmin mode) — skipped where the stored frame is not eligible for that row's
 // query frame (the frames are packed by descending eligibility, so that is the last few slots of a column only).
 template <int THREADS, int QPT, int ARGMIN_MODE, bool WRITE_KEYS, bool PACKED = false>
-__global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : 6) void k_score_rowlane(ScoreArgs a) {
+// Waves per SIMD the register budget is cut for: 6 (80 VGPRs) for the throughput kernels, 8 for the 6-rows-per-lane A/B,
+// 5 (96 VGPRs) for the per-distance-key kernel of the pair mode — two values more than 80 are live in it, its launches
+// are a few dozen workgroups, and occupancy is not what they wait for.
+__global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : (ARGMIN_MODE == 2 ? 5 : 6)) void k_score_rowlane(ScoreArgs a) {
     // ARGMIN_MODE = 0 with WRITE_KEYS = true writes the best DISTANCE per query row (split mode, see k_finalize_pairs)
     constexpr bool ARGMIN = ARGMIN_MODE != 0;
     constexpr bool GROUPED = ARGMIN_MODE == 1;
@@ -172,7 +168,7 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : 6) void k_score
     __shared__ uint32_t red_min[2];
     __shared__ uint32_t red_sum[2];
     __shared__ uint32_t red_idx[2];
-    __shared__ uint32_t lane_key[GROUPED ? THREADS * QPT : 1];
+    __shared__ uint32_t lane_key[(GROUPED || PACKED) ? THREADS * QPT : 1];   // GROUPED: (dist, group) keys; PACKED: also the epilogue's staging
     __shared__ uint32_t lane_meta[PACKED ? THREADS * QPT : 1];     // PACKED: packed position of the row's frame, 0xFFFFFFFF = idle
 
     const int tid = threadIdx.x;
@@ -220,21 +216,35 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : 6) void k_score
     uint32_t q[QPT][8];
     auto valid = [&](int j) { return j * THREADS + tid < nq; };     // recomputed where needed: keeps VGPRs <= 80
     if (PACKED) {
-        uint32_t c = it.out_offset;            // packed position that holds the column's first row; rows ascend with j
-        const uint32_t v0 = it.q_frame * (uint32_t)(THREADS * QPT);
+        // Phase 1 (a rolled loop, on purpose): the packed position of each of this lane's rows goes to its LDS word.
+        // Rows ascend with j, so the position only moves forward from the column's first one (it.out_offset).  Kept
+        // out of the unrolled code below so that no position stays in a register across the scan: the main loop has
+        // none to spare.
+        {
+            uint32_t c = it.out_offset;
+            const uint32_t v0 = it.q_frame * (uint32_t)(THREADS * QPT);
+#pragma unroll 1
+            for (int j = 0; j < QPT; ++j) {
+                const uint32_t v = v0 + (uint32_t)(j * THREADS + tid);
+                uint32_t meta = 0xFFFFFFFFu;
+                if (j * THREADS + tid < nq) {
+                    while (a.pk_vstart[c + 1] <= v) ++c;            // v < pk_vstart[pk_n]: stops at c < pk_n
+                    meta = c;
+                }
+                lane_meta[j * THREADS + tid] = meta;
+            }
+        }
+        // Phase 2: load the rows (row r of frame pk_qframe[c]; a frame above 2048 rows spans columns)
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
-            const uint32_t v = v0 + (uint32_t)(j * THREADS + tid);
+            __builtin_amdgcn_sched_barrier(0);      // one row at a time: interleaving the 8 address chains costs registers
             uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
-            uint32_t meta = 0xFFFFFFFFu;
-            if (j * THREADS + tid < nq) {
-                while (a.pk_vstart[c + 1] <= v) ++c;                // v < pk_vstart[pk_n]: stops at c < pk_n
-                const uint32_t r = v - a.pk_vstart[c];              // row inside its frame (a frame above 2048 rows spans columns)
+            const uint32_t c = lane_meta[j * THREADS + tid];
+            if (c != 0xFFFFFFFFu) {
+                const uint32_t r = it.q_frame * (uint32_t)(THREADS * QPT) + (uint32_t)(j * THREADS + tid) - a.pk_vstart[c];
                 const uint4* qb = reinterpret_cast<const uint4*>(a.q_rows + (size_t)a.pk_qframe[c] * a.q_stride_words);
                 lo = qb[(size_t)r * 2]; hi = qb[(size_t)r * 2 + 1];
-                meta = c;
             }
-            lane_meta[j * THREADS + tid] = meta;
             q[j][0] = lo.x; q[j][1] = lo.y; q[j][2] = lo.z; q[j][3] = lo.w;
             q[j][4] = hi.x; q[j][5] = hi.y; q[j][6] = hi.z; q[j][7] = hi.w;
         }
@@ -324,18 +334,27 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : 6) void k_score
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (GROUPED) {       // from here on best[j] is the packed key dist << 22 | first train row (0xFFFFFFFF: no train rows)
+        if (GROUPED && !PACKED) {   // from here on best[j] is the packed key dist << 22 | first train row (0xFFFFFFFF: no train rows)
 #pragma unroll
             for (int j = 0; j < QPT; ++j) best[j] = lane_key[j * THREADS + tid];
         }
 
         if (PACKED) {        // best distance / key of every (eligible pair, query row); k_finalize_bulk forms the records
+            // staged through the lane's LDS words and written by a ROLLED loop: a handful of live registers instead of
+            // eight address chains (the scan's 64 query-row registers stay untouched, nothing spills)
+            if (!GROUPED) {
 #pragma unroll
+                for (int j = 0; j < QPT; ++j) lane_key[j * THREADS + tid] = best[j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t col0 = it.q_frame * (uint32_t)(THREADS * QPT);      // first virtual row of the column (wave-uniform)
+            asm volatile("" : "+s"(col0));       // opaque here: `col0 + tid` must not be hoisted above the scan, where it would cost a register
+#pragma unroll 1
             for (int j = 0; j < QPT; ++j) {
                 const uint32_t c = lane_meta[j * THREADS + tid];
                 if (c == 0xFFFFFFFFu) continue;
-                const uint32_t r = it.q_frame * (uint32_t)(THREADS * QPT) + (uint32_t)(j * THREADS + tid) - a.pk_vstart[c];
-                if (slot < a.pk_elig[c]) a.pk_dist[((size_t)a.pk_pairs[c] + slot) * a.pk_stride + r] = best[j];
+                const uint32_t r = col0 + (uint32_t)(j * THREADS + tid) - a.pk_vstart[c];
+                if (slot < a.pk_elig[c]) a.pk_dist[((size_t)a.pk_pairs[c] + slot) * a.pk_stride + r] = lane_key[j * THREADS + tid];
             }
             continue;
         }
