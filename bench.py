@@ -621,8 +621,11 @@ def main():
                          "traffic_source": None if traffic is None else
                          "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command "
                          "(gfx950 corrections applied), NOT measured in this run",
-                         "kernel": "k_score_rowlane<256, 8, %d, false, %s>%s" % (1 if argmin_api and not fused else 0, "true" if packed else "false",
-                                                                                  " (argmin)" if argmin_api and not fused else ""),
+                         "kernel": ("k_score_trainlane<%s, false>" % ("true" if args.variant == 3 else "false")) if args.variant in (2, 3) else
+                                   "k_score_rowlane<%d, 8, %d, false, %s>%s" % (
+                                       256 if packed else (64 if n_desc <= 512 else 128 if n_desc <= 1024 else 192 if n_desc <= 1536 else 256),
+                                       1 if argmin_api and not fused else 0, "true" if packed else "false",
+                                       " (argmin)" if argmin_api and not fused else ""),
                          "route": "packed: query rows of consecutive frames share full 2048-row workgroups; records formed by "
                                   "k_finalize_bulk" if packed else "one workgroup per (query frame, run of stored frames)",
                          "fold_kernel_ms": float(np.mean(fold_ms)) if fold_ms else None,
