@@ -164,3 +164,50 @@ def test_packed_is_the_automatic_choice_for_orb_sized_frames(matcher, oracle, pk
     finally:
         matcher.set_params(min_gap=30)
         matcher.clear()
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_packed_equals_plain_on_random_shapes(matcher, oracle, pkg, seed):
+    """Differential: the packed and the plain route (two different kernels + a fold kernel vs in-kernel reductions)
+    must write the same bytes — records and index checksums — on random ragged databases of random size, gap, id spacing
+    and item size; a sample of pairs pins both to the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n_frames = int(rng.integers(20, 140))
+    max_desc = int(rng.choice([40, 300, 777, 1500, 2048]))
+    fs = pkg.synth.make_frames(n_frames, max_desc, seed=2000 + seed, ragged=True, dup_frac=float(rng.uniform(0.0, 0.5)))
+    fs.counts[:] = rng.integers(0, max_desc + 1, n_frames)
+    fs.counts[int(rng.integers(0, n_frames))] = max_desc
+    ids = (np.cumsum(rng.integers(1, 4, n_frames)) - 1).astype(np.int32)
+    gap = int(rng.integers(0, 6))
+    matcher.set_params(min_gap=gap)
+    matcher.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, int(rng.choice([0, 1, 3, 8])))
+    try:
+        matcher.clear()
+        for f in range(n_frames):
+            matcher.append(int(ids[f]), fs.frame(f))
+        n, offs = matcher.all_vs_all_plan()
+        if n == 0:
+            return
+        res = {}
+        for mode in (0, 1, 2):
+            got, got2, sums, _ = _run(matcher, pkg, n, mode)
+            np.testing.assert_array_equal(got, got2)
+            res[mode] = (got, sums)
+        for mode in (1, 2):
+            np.testing.assert_array_equal(res[mode][0], res[0][0], err_msg=f"records, packed={mode}")
+            np.testing.assert_array_equal(res[mode][1], res[0][1], err_msg=f"index checksums, packed={mode}")
+        p = oracle.default_params(min_gap=gap)
+        pq, pt = [], []
+        for c in range(n_frames):
+            e = int(offs[c + 1] - offs[c])
+            for t in rng.choice(e, size=min(e, 2), replace=False) if e else []:
+                pq.append(c); pt.append(int(t))
+        want, wsums = oracle.fast_score_pairs_idx(fs.rows, fs.counts, pq, pt, p, n_threads=8)
+        k = offs[pq].astype(np.int64) + np.array(pt, np.int64)
+        np.testing.assert_array_equal(res[1][0][k], want)
+        np.testing.assert_array_equal(res[1][1][k], wsums)
+    finally:
+        matcher.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, 0)
+        matcher.set_tuning(pkg.capi.TUNE_PACKED, -1)
+        matcher.set_params(min_gap=30)
+        matcher.clear()
