@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
         const int n_places = 4;
         std::vector<std::vector<uint8_t>> place(n_places, std::vector<uint8_t>((size_t)rows * 32));
         for (auto& p : place) for (auto& b : p) b = (uint8_t)next_u64();
+        std::vector<std::vector<uint8_t>> all_frames;
         for (int f = 0; f < n_frames; ++f) {
             std::vector<uint8_t> d = place[f % n_places];      // revisit the place every 4 frames ...
             for (int r = 0; r < rows; ++r) {
@@ -41,6 +42,22 @@ int main(int argc, char** argv) {
             system.processFrame(d.data(), rows, rows, f);
             for (size_t i = 0; i < d.size(); ++i) printf("%02x", d[i]);
             printf("\n");
+            all_frames.push_back(std::move(d));
+        }
+        {   // the same sequence through processFrames (micro-batched scoring): same loop closures, same consecutive matches
+            loop_closing::LoopClosing batched(0.15, 5);
+            std::vector<loop_closing::LoopClosing::FrameInput> in;
+            for (int f = 0; f < n_frames; ++f) in.push_back({all_frames[(size_t)f].data(), rows, rows, f});
+            batched.processFrames(in.data(), (int)in.size());
+            bool same = batched.getLoopClosures().size() == system.getLoopClosures().size() &&
+                        batched.getConsecutiveMatches().size() == system.getConsecutiveMatches().size();
+            for (size_t i = 0; same && i < batched.getLoopClosures().size(); ++i) {
+                const auto& a = batched.getLoopClosures()[i];
+                const auto& b = system.getLoopClosures()[i];
+                same = a.current_frame_id == b.current_frame_id && a.matched_frame_id == b.matched_frame_id &&
+                       a.num_matches == b.num_matches && a.similarity_score == b.similarity_score;
+            }
+            printf("BATCHED_EQUAL %d\n", same ? 1 : 0);
         }
         printf("FRAMES %zu LOOPS %zu\n", system.getFrames().size(), system.getLoopClosures().size());
         for (const auto& c : system.getLoopClosures())

@@ -50,6 +50,7 @@ def test_cpp_demo_matches_oracle(tmp_path, pkg, oracle):
     for l, w in zip(ms, om):
         assert (int(l[1]), int(l[2]), int(l[3]), float(l[4])) == (int(w["query_idx"]), int(w["train_idx"]), 0, float(w["distance"]))
     assert any(l.startswith("EXPECTED_EXCEPTION") for l in lines)
+    assert "BATCHED_EQUAL 1" in lines                            # processFrames (micro-batches) == processFrame per frame
     # matchLoopClosures: list sizes == num_matches of the busiest frame's closures
     rel = [l.split() for l in lines if l.startswith("RELISTS ")][0]
     busiest = int(rel[1])
