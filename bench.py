@@ -515,7 +515,7 @@ def main():
     # the same workload through the OTHER row-per-lane kernel, reported beside the headline number: distance-only when the
     # headline is the argmin kernel, and the other way round
     other_ms = None
-    if args.variant in (0, 1) and not fused:
+    if args.variant in (0, 1) and not fused and not (multi and long_step):      # (N = 8 / cfg3: two more 8 s passes per rank buy nothing)
         ms = []
         for _ in range(1 if long_step else 2):
             if argmin_api:
