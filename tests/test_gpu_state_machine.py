@@ -1,0 +1,178 @@
+"""Randomised API sequences against a Python model of the database (K10 / K11 in the time dimension): appends (host
+and device rows), clear, snapshot round trips, parameter / kernel-variant / tuning changes, bulk searches (records,
+index checksums, fused loop test), online queries with several tickets in flight and appends between them, stored-frame
+detectLoops and match lists — every result compared with the oracle on the model's frames.  What this hunts: state that
+outlives its validity (cached plans, operand images, tickets, staging buffers, stream ordering between the handle's
+stream, the copy stream and the query slots' streams)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MAX_ROWS = 140
+
+
+class Model:
+    def __init__(self):
+        self.ids, self.frames = [], []
+
+    def arrays(self, extra=()):
+        fr = self.frames + list(extra)
+        rows = np.zeros((max(len(fr), 1), MAX_ROWS, 32), np.uint8)
+        counts = np.zeros(max(len(fr), 1), np.int32)
+        for i, f in enumerate(fr):
+            rows[i, : len(f)] = f
+            counts[i] = len(f)
+        return rows, counts
+
+    def elig(self, qid, gap):
+        return [i for i, s in enumerate(self.ids) if qid - s >= max(gap, 1)]
+
+
+def _frame(rng, alphabet):
+    n = int(rng.choice([0, 1, 3, 17, 64, 65, 100, MAX_ROWS]))
+    f = alphabet[rng.integers(0, len(alphabet), n)].copy()
+    if n and rng.random() < 0.5:
+        f[rng.integers(0, n), rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+    return f
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_api_sequences_equal_oracle(pkg, oracle, tmp_path, seed):
+    rng = np.random.default_rng(9000 + seed)
+    alphabet = rng.integers(0, 256, (int(rng.integers(2, 9)), 32), dtype=np.uint8)
+    model = Model()
+    st = dict(gap=2, cross=0, variant=0)
+    next_id = 0
+    pending = []                                  # (ticket, kind, query frames, query ids, model size at submit)
+    with pkg.Matcher() as m:
+        m.set_params(min_gap=st["gap"], min_matches=1, sim_threshold=0.0)
+        d_frame = m.dev_alloc(MAX_ROWS * 32)
+
+        def params():
+            return oracle.default_params(min_gap=st["gap"], min_matches=1, sim_threshold=0.0, cross_check=st["cross"])
+
+        def want_query(q, qid, n_stored):
+            rows, counts = model.arrays([q])
+            el = [i for i in model.elig(qid, st["gap"]) if i < n_stored]
+            sc, _ = oracle.fast_score_pairs_idx(rows, counts, [len(model.frames)] * len(el), el, params(), n_threads=2)
+            return sc
+
+        def collect_all():
+            while pending:
+                t, kind, qs, qids, n_stored, p_at = pending.pop(int(rng.integers(0, len(pending))))
+                saved = (st["gap"], st["cross"])
+                st["gap"], st["cross"] = p_at                        # a ticket's records follow the parameters at submit
+                if kind == "one":
+                    sc, ids = m.query_collect(t)
+                    np.testing.assert_array_equal(sc, want_query(qs[0], qids[0], n_stored))
+                    assert ids.tolist() == [model.ids[i] for i in model.elig(qids[0], st["gap"]) if i < n_stored]
+                else:
+                    sc, offs = m.query_collect_batch(t)
+                    for k, (q, qid) in enumerate(zip(qs, qids)):
+                        np.testing.assert_array_equal(sc[int(offs[k]): int(offs[k + 1])], want_query(q, qid, n_stored))
+                st["gap"], st["cross"] = saved
+
+        ran = {}
+        for step in range(300):
+            op = rng.choice(["append", "append", "append", "append_dev", "bulk", "bulk", "loops", "query", "submit", "batch",
+                             "collect", "detect", "match", "params", "variant", "tuning", "snapshot", "clear"])
+            op = str(op)
+            ran[op] = ran.get(op, 0) + 1
+            if op in ("append", "append_dev"):
+                f = _frame(rng, alphabet)
+                next_id += int(rng.integers(1, 4))
+                if op == "append_dev" and len(f):
+                    m.dev_upload(d_frame, np.ascontiguousarray(f))
+                    m.append_device(next_id, d_frame, len(f))
+                    m.sync()                                          # d_frame is reused by the next device append
+                else:
+                    m.append(next_id, f)
+                model.ids.append(next_id); model.frames.append(f)
+            elif op == "clear" and rng.random() < 0.3:
+                collect_all()
+                m.clear(); model.ids.clear(); model.frames.clear()
+            elif op == "snapshot" and model.frames:
+                collect_all()
+                path = str(tmp_path / f"db_{seed}.bin")
+                m.save(path)
+                if rng.random() < 0.5:
+                    m.clear()
+                m.load(path)
+                assert len(m) == len(model.frames)
+            elif op == "params":
+                collect_all()                                         # (a ticket is compared under the parameters at submit)
+                st["gap"] = int(rng.integers(0, 5))
+                st["cross"] = int(rng.choice([0, 0, 0, 1, 2]))
+                m.set_params(min_gap=st["gap"], cross_check=st["cross"])
+            elif op == "variant":
+                st["variant"] = int(rng.choice([0, 0, 1, 4, 5]))
+                m.set_kernel_variant(st["variant"])
+            elif op == "tuning":
+                m.set_tuning(pkg.capi.TUNE_PACKED, int(rng.choice([-1, 0, 1, 2])))
+                m.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, int(rng.choice([0, 1, 2, 5])))
+                m.set_tuning(pkg.capi.TUNE_ONLINE_SPLIT, int(rng.choice([-1, 0, 1, 2, 4, 16, 32])))
+                m.set_tuning(pkg.capi.TUNE_ONLINE_STREAMS, int(rng.choice([0, 1])))
+            elif op in ("bulk", "loops") and model.frames:
+                rows, counts = model.arrays()
+                pq, pt, offs = [], [], [0]
+                for c, cid in enumerate(model.ids):
+                    for i in model.elig(cid, st["gap"]):
+                        pq.append(c); pt.append(i)
+                    offs.append(len(pq))
+                want, wsums = oracle.fast_score_pairs_idx(rows, counts, pq, pt, params(), n_threads=2)
+                n, goffs = m.all_vs_all_plan()
+                assert n == len(pq) and goffs.astype(np.int64).tolist() == offs
+                if n == 0:
+                    continue
+                if op == "bulk":
+                    d, ds = m.dev_alloc(n * 8), m.dev_alloc(n * 4)
+                    got, sums = np.zeros(n, want.dtype), np.zeros(n, np.uint32)
+                    m.all_vs_all(d, n); m.sync(); m.dev_download(d, got)
+                    np.testing.assert_array_equal(got, want, err_msg=f"step {step} {st}")
+                    m.all_vs_all_argmin(d, n, ds); m.sync(); m.dev_download(d, got); m.dev_download(ds, sums)
+                    m.dev_free(d); m.dev_free(ds)
+                    np.testing.assert_array_equal(got, want, err_msg=f"step {step} argmin {st}")
+                    np.testing.assert_array_equal(sums, wsums, err_msg=f"step {step} checksums {st}")
+                else:
+                    cands, npairs = m.all_vs_all_loops(cap=n)
+                    keep = [(model.ids[pq[k]], model.ids[pt[k]], int(want[k]["good_count"])) for k in range(n)
+                            if oracle.loop_test(int(want[k]["good_count"]), int(counts[pq[k]]), int(counts[pt[k]]), params())[0]]
+                    assert npairs == n
+                    assert [(int(r["current_frame_id"]), int(r["matched_frame_id"]), int(r["num_matches"])) for r in cands] == keep
+            elif op == "query":
+                q = _frame(rng, alphabet)
+                qid = next_id + int(rng.integers(-3, 6))
+                sc, ids = m.query_scores(q, qid)
+                np.testing.assert_array_equal(sc, want_query(q, qid, len(model.frames)), err_msg=f"step {step} {st}")
+            elif op in ("submit", "batch") and len(pending) < 3:        # the synchronous calls below need the fourth slot
+                k = 1 if op == "submit" else int(rng.integers(1, 5))
+                qs = [_frame(rng, alphabet) for _ in range(k)]
+                qids = [next_id + 1 + j for j in range(k)]            # ascending; may or may not span min_gap: each query only
+                if op == "submit":                                    # ever sees the STORED frames, never its batch mates
+                    t = m.query_submit(qs[0], qids[0])
+                    pending.append((t, "one", qs, qids, len(model.frames), (st["gap"], st["cross"])))
+                else:
+                    t = m.query_submit_batch(qs, qids)
+                    pending.append((t, "batch", qs, qids, len(model.frames), (st["gap"], st["cross"])))
+            elif op == "collect":
+                collect_all()
+            elif op == "detect" and model.frames:
+                cur = int(rng.integers(0, len(model.frames)))
+                got = m.detect_loops(model.ids[cur])
+                rows, counts = model.arrays()
+                wc = oracle.detect_loops(rows, counts, np.array(model.ids, np.int32), cur, params())
+                for f in ("matched_frame_id", "num_matches", "similarity_score"):
+                    np.testing.assert_array_equal(got[f], wc[f], err_msg=f"step {step} {st}")
+            elif op == "match" and len(model.frames) >= 2:
+                a, b = (int(x) for x in rng.integers(0, len(model.frames), 2))
+                got, md = m.match_stored(model.ids[a], model.ids[b])
+                om, omd = oracle.match_features(model.frames[a], model.frames[b], params())
+                assert md == omd or len(om) == 0
+                np.testing.assert_array_equal(got, om.astype(got.dtype), err_msg=f"step {step} {st}")
+        collect_all()
+        m.dev_free(d_frame)
+        print(f"seed {seed}: {sorted(ran.items())}, {len(model.frames)} frames at the end")
+        assert all(ran.get(k, 0) > 0 for k in ("append", "bulk", "loops", "query", "submit", "batch", "detect", "match", "params", "variant", "tuning"))
