@@ -176,3 +176,75 @@ def test_random_api_sequences_equal_oracle(pkg, oracle, tmp_path, seed):
         m.dev_free(d_frame)
         print(f"seed {seed}: {sorted(ran.items())}, {len(model.frames)} frames at the end")
         assert all(ran.get(k, 0) > 0 for k in ("append", "bulk", "loops", "query", "submit", "batch", "detect", "match", "params", "variant", "tuning"))
+
+
+@pytest.mark.parametrize("world,seed", [(2, 0), (3, 1), (8, 2), (3, 3)])
+def test_random_group_sequences_equal_single_handle(pkg, oracle, world, seed):
+    """The same idea for the multi-device path: a loopback group of W shards (W matchers on the one device, exchange steps
+    as device-local copies) and ONE matcher receive the same random calls — appends of frames of changing size (the
+    shard arenas must keep one geometry), clear, parameter changes, bulk searches, online single / micro-batch queries,
+    detectLoops — and must answer with the same bytes; a sample of bulk records is pinned to the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    alphabet = rng.integers(0, 256, (int(rng.integers(2, 9)), 32), dtype=np.uint8)
+    model = Model()
+    gap, next_id = 2, 0
+    p0 = pkg.default_params()
+    p0.min_gap, p0.min_matches, p0.sim_threshold = gap, 1, 0.0
+    with pkg.Group(p0, n_devices=world, loopback_device=0) as g, pkg.Matcher(p0) as m:
+        ran = {}
+        for step in range(150):
+            op = str(rng.choice(["append", "append", "append", "append", "bulk", "bulk", "query", "batch", "detect", "params", "clear"]))
+            ran[op] = ran.get(op, 0) + 1
+            if op == "append":
+                f = _frame(rng, alphabet)
+                next_id += int(rng.integers(1, 4))
+                g.append(next_id, f); m.append(next_id, f)
+                model.ids.append(next_id); model.frames.append(f)
+            elif op == "clear" and rng.random() < 0.25:
+                g.clear(); m.clear(); model.ids.clear(); model.frames.clear()
+            elif op == "params":
+                gap = int(rng.integers(0, 5))
+                p = pkg.default_params()
+                p.min_gap, p.min_matches, p.sim_threshold = gap, 1, 0.0
+                g.set_params(p); m.set_params(min_gap=gap)
+            elif op == "bulk":
+                merged, offs = g.all_vs_all()
+                n, moffs = m.all_vs_all_plan()
+                assert len(merged) == n and np.array_equal(np.asarray(offs, np.int64), moffs.astype(np.int64)), f"step {step}"
+                if n:
+                    d = m.dev_alloc(n * 8)
+                    single = np.zeros(n, pkg.capi.SCORE_DTYPE)
+                    m.all_vs_all(d, n); m.sync(); m.dev_download(d, single); m.dev_free(d)
+                    np.testing.assert_array_equal(merged, single, err_msg=f"step {step} world {world}")
+                    rows, counts = model.arrays()
+                    pq, pt = [], []
+                    for c, cid in enumerate(model.ids):
+                        el = model.elig(cid, gap)
+                        if el:
+                            pq.append(c); pt.append(el[int(rng.integers(0, len(el)))])
+                    want, _ = oracle.fast_score_pairs_idx(rows, counts, pq, pt, oracle.default_params(min_gap=gap), n_threads=2)
+                    np.testing.assert_array_equal(merged[moffs[pq].astype(np.int64) + np.array(pt, np.int64)], want)
+            elif op == "query":
+                q = _frame(rng, alphabet)
+                qid = next_id + int(rng.integers(-3, 6))
+                a, ia = g.query_scores(q, qid)
+                b, ib = m.query_scores(q, qid)
+                np.testing.assert_array_equal(a, b, err_msg=f"step {step}")
+                np.testing.assert_array_equal(ia, ib)
+            elif op == "batch":
+                k = int(rng.integers(1, 6))
+                qs = [_frame(rng, alphabet) for _ in range(k)]
+                qids = [next_id + 1 + j for j in range(k)]
+                a, oa = g.query_scores_batch(qs, qids)
+                t = m.query_submit_batch(qs, qids)
+                b, ob = m.query_collect_batch(t)
+                np.testing.assert_array_equal(oa, ob)
+                np.testing.assert_array_equal(a, b, err_msg=f"step {step}")
+            elif op == "detect" and model.frames:
+                q = _frame(rng, alphabet)
+                qid = next_id + 2
+                a = g.detect_loops(qid, q)
+                b = m.detect_loops(qid, q)
+                for f in ("matched_frame_id", "num_matches", "similarity_score"):
+                    np.testing.assert_array_equal(a[f], b[f], err_msg=f"step {step}")
+        assert all(ran.get(k, 0) > 0 for k in ("append", "bulk", "query", "batch", "detect", "params"))
