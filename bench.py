@@ -533,6 +533,7 @@ def main():
     if args.variant in (0, 1) and not fused and not multi and not args.no_extras:
         mfma = {}
         ref = scores.clone()
+        ref_idx = idx_sums.clone()
         for v, name, peak in ((4, "int8", MFMA_I8_PEAK_OPS), (5, "fp4", MFMA_FP4_PEAK_OPS)):
             m.set_kernel_variant(v)
             ms = []
@@ -546,6 +547,18 @@ def main():
                           "records_equal_to_headline": bool(torch.equal(scores, ref)),
                           "roofline": {"bound": "mfma", "achieved": ops / 1e12, "peak": peak / 1e12, "unit": "TOP/s",
                                        "frac": ops / peak}}
+            if argmin_api:
+                # the argmin form on the matrix cores: first tile that reaches the best dot product, then an exact
+                # XOR + popcount re-scan of that one tile -> the same index checksums as the headline kernel
+                ms = []
+                for _ in range(2):
+                    m.all_vs_all_argmin(scores.data_ptr(), n_local, idx_sums.data_ptr(), **q_args)
+                    ms.append(m.launch_info().kernel_ms)
+                torch.cuda.synchronize(dev)
+                a_ms = float(np.min(ms))
+                mfma[name]["argmin"] = {"ms_per_pass": a_ms, "distances_per_s": local_dist / (a_ms * 1e-3),
+                                        "records_equal_to_headline": bool(torch.equal(scores, ref)),
+                                        "index_checksums_equal_to_headline": bool(torch.equal(idx_sums, ref_idx))}
         m.set_kernel_variant(0)
         search(scores.data_ptr(), n_local)
         m.sync()

@@ -267,8 +267,10 @@ LCM_API int  lcm_last_bulk_scores(const lcm_handle* h, const void** d_scores, si
  * runs the search on v_mfma_i32_32x32x32_i8 over a +1 / -1 int8 image of
  * the descriptors (<q,t> = 256 - 2 d, exact) to MEASURE what that rule costs; same records bit for bit.  5 = the same
  * on the block-scaled fp4 instruction (v_mfma_scale_f32_32x32x64_f8f6f4, +1/-1 as e2m1, all scales 1.0, exact in the
- * f32 accumulator).  4 / 5 serve the bulk search and the online queries (single, stored-frame, micro-batched); pair
- * mode, cross_check and lcm_all_vs_all_argmin keep running the vector-ALU kernels under them. */
+ * f32 accumulator).  4 / 5 serve the bulk search — lcm_all_vs_all_argmin included: the matrix instruction finds the
+ * first 32-row tile that reaches the best dot product, an exact XOR + popcount re-scan of that tile finds the row —
+ * and the online queries (single, stored-frame, micro-batched); pair mode and cross_check keep running the
+ * vector-ALU kernels under them, as do query frames above 2048 rows. */
 LCM_API int  lcm_set_kernel_variant(lcm_handle* h, int variant);
 
 /* ---- multi-GPU: one process, W devices, stored frames sharded cyclically by arrival position ------------------- */

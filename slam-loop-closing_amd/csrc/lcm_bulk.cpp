@@ -255,11 +255,11 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
         }
         return cross_score_prefixes(h, qbase, row0.data(), nqv.data(), ev.data(), n_q_frames, (lcm_score*)d_scores, d_idx_sums);
     }
-    if ((h->variant == 4 || h->variant == 5) && !d_idx_sums && P.max_q_rows <= lcm::MAX_FUSED_QUERY_ROWS) {      // (bigger query frames: packed vector-ALU route)
+    if ((h->variant == 4 || h->variant == 5) && P.max_q_rows <= lcm::MAX_FUSED_QUERY_ROWS) {      // (bigger query frames: packed vector-ALU route)
         std::vector<int> nqv((size_t)n_q_frames);
         for (int c = 0; c < n_q_frames; ++c) nqv[(size_t)c] = self ? h->frames[(size_t)c].n : qc[(size_t)c];
         return mfma_bulk(h, self, self ? h->d_rows : (const uint8_t*)d_query_rows, d_query_counts,
-                         (uint32_t)(self ? h->stride_rows : q_stride_rows), q_frame_of, nqv.data(), n_q_frames, P.offsets, (lcm_score*)d_scores);
+                         (uint32_t)(self ? h->stride_rows : q_stride_rows), q_frame_of, nqv.data(), n_q_frames, P.offsets, (lcm_score*)d_scores, d_idx_sums);
     }
     lcm::ScoreArgs a{};
     a.q_rows = self ? (const uint32_t*)h->d_rows : (const uint32_t*)d_query_rows;

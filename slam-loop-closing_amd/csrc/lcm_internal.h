@@ -226,7 +226,8 @@ int cross_score_prefixes(lcm_handle* h, const uint8_t* d_qbase, const uint32_t* 
 // ---- lcm_mfma_host.cpp: opt-in matrix-core variants 4 / 5
 int mfma_online(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int pitch_rows, int B, const int* nq, const int* elig);
 int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int32_t* d_q_counts, uint32_t q_pitch_rows,
-              const uint32_t* q_frame_of, const int* nqv, int n_q, const std::vector<size_t>& offsets, lcm_score* d_scores);
+              const uint32_t* q_frame_of, const int* nqv, int n_q, const std::vector<size_t>& offsets, lcm_score* d_scores,
+              uint32_t* d_idx_sums);     // d_idx_sums non-NULL: the argmin form (keys + index checksums)
 // ---- lcm_bulk.cpp
 // Bulk search behind lcm_all_vs_all / lcm_all_vs_all_argmin.  q_frame_of (optional, n_q_frames entries): query frame c
 // lives at index q_frame_of[c] of d_query_rows / d_query_counts instead of index c (the group's rank-major gathered

@@ -191,6 +191,12 @@ struct MfmaArgs {
     const MfmaItem* items;
     uint32_t*       dist;          // dist[(out_offset + s - pair_base) * 2048 + query row]
     uint32_t        pair_base;
+    // ARGMIN form (argmin != 0): dist receives packed keys `distance << 22 | first train row attaining it`.  The matrix
+    // instruction finds, per query row, the best dot product and the FIRST 32-row tile that reaches it; the lane then
+    // re-scans that one tile on the vector ALU over the ORIGINAL packed rows (exact XOR + popcount) for the first row.
+    int32_t         argmin;
+    const uint32_t* q_rows;  uint32_t q_stride_words;    // packed query frames (frame f at q_rows + f * q_stride_words)
+    const uint32_t* db_rows; uint32_t db_stride_words;   // packed stored frames
 };
 hipError_t launch_score_mfma(const MfmaArgs& a, uint32_t n_items, hipStream_t st);
 

@@ -51,6 +51,32 @@ __device__ __forceinline__ int max16(const v16i& c) {
     return max(m, c[15]);
 }
 
+// ARGMIN epilogue: the packed key (distance << 22 | row) of query row `qrow` of frame `qf` over the 32 stored rows of
+// tile `tile` of slot `slot` — exact XOR + popcount on the packed rows, four rows per round trip.  The tile is the
+// first one that reached the best dot product, so its minimum IS the frame's first minimum.
+__device__ __forceinline__ uint32_t rescan_tile(const MfmaArgs& a, uint32_t qf, uint32_t qrow, uint32_t slot, uint32_t tile, int nt) {
+    const uint4* qp = reinterpret_cast<const uint4*>(a.q_rows + (size_t)qf * a.q_stride_words + (size_t)qrow * 8);
+    const uint4 qlo = qp[0], qhi = qp[1];
+    const uint4* tp = reinterpret_cast<const uint4*>(a.db_rows + (size_t)slot * a.db_stride_words);
+    const uint32_t r0 = tile * 32u, r1 = min(r0 + 32u, (uint32_t)nt);
+    uint32_t key = 0xFFFFFFFFu;
+    for (uint32_t r = r0; r < r1; r += 4) {
+        uint4 lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t rr = min(r + (uint32_t)k, r1 - 1);          // past the end: the last row again (higher index, cannot win)
+            lo[k] = tp[(size_t)rr * 2]; hi[k] = tp[(size_t)rr * 2 + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t d = __popc(qlo.x ^ lo[k].x) + __popc(qlo.y ^ lo[k].y) + __popc(qlo.z ^ lo[k].z) + __popc(qlo.w ^ lo[k].w) +
+                               __popc(qhi.x ^ hi[k].x) + __popc(qhi.y ^ hi[k].y) + __popc(qhi.z ^ hi[k].z) + __popc(qhi.w ^ hi[k].w);
+            key = min(key, (d << KEY_SHIFT) | (r + (uint32_t)k));
+        }
+    }
+    return key;
+}
+
 __global__ __launch_bounds__(256, 4) void k_score_mfma(MfmaArgs a) {
     __shared__ uint4 atile[2][512];                             // two 8 KiB stored-frame tiles (A operands)
     const MfmaItem it = a.items[blockIdx.x];
@@ -80,6 +106,7 @@ __global__ __launch_bounds__(256, 4) void k_score_mfma(MfmaArgs a) {
         const uint32_t nt_tiles = (uint32_t)(nt + 31) / 32;
         const uint4* tb = reinterpret_cast<const uint4*>(a.db_pm1 + (size_t)slot * a.db_tiles_per_frame * PM1_TILE_BYTES);
         int best0 = -0x7FFFFFFF, best1 = -0x7FFFFFFF;
+        uint32_t bt0 = 0, bt1 = 0;                               // first tile that reached best0 / best1 (argmin form)
         if (nt_tiles > 0) {
             // stage tile 0, then: compute tile t from LDS while tile t + 1 travels global -> registers -> LDS
             uint4 g0 = tb[tid], g1 = tb[256 + tid];
@@ -96,15 +123,27 @@ __global__ __launch_bounds__(256, 4) void k_score_mfma(MfmaArgs a) {
                     acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0[ks], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1[ks], acc1, 0, 0, 0);
                 }
-                best0 = max(best0, max16(acc0));
-                best1 = max(best1, max16(acc1));
+                const int m0 = max16(acc0), m1 = max16(acc1);
+                if (m0 > best0) { best0 = m0; bt0 = t; }        // strict: the FIRST tile keeps the title
+                if (m1 > best1) { best1 = m1; bt1 = t; }
                 if (t + 1 < nt_tiles) { atile[cur ^ 1][tid] = g0; atile[cur ^ 1][256 + tid] = g1; }
                 __syncthreads();                                 // tile t + 1 visible; tile t's buffer free for t + 2
             }
         }
         // a query column's 32 stored rows of a tile sit in 16 registers of lane l and 16 of lane l + 32
-        best0 = max(best0, __shfl_xor(best0, 32, 64));
-        best1 = max(best1, __shfl_xor(best1, 32, 64));
+        {
+            const int o0 = __shfl_xor(best0, 32, 64), o1 = __shfl_xor(best1, 32, 64);
+            const uint32_t p0 = (uint32_t)__shfl_xor((int)bt0, 32, 64), p1 = (uint32_t)__shfl_xor((int)bt1, 32, 64);
+            if (o0 > best0 || (o0 == best0 && p0 < bt0)) { best0 = o0; bt0 = p0; }
+            if (o1 > best1 || (o1 == best1 && p1 < bt1)) { best1 = o1; bt1 = p1; }
+        }
+        if (a.argmin) {
+            // both half-waves now hold (best, first tile) of both query tiles: lanes 0-31 finish tile 0's rows, 32-63 tile 1's
+            uint32_t* out = a.dist + (size_t)(it.out_offset + s - a.pair_base) * MAX_FUSED_QUERY_ROWS;
+            const uint32_t r = qt0 * 32 + (uint32_t)lane;                        // = r0 for lane < 32, r1 for lane >= 32
+            if (r < (uint32_t)nq) out[r] = nt > 0 ? rescan_tile(a, it.q_frame, r, slot, lane < 32 ? bt0 : bt1, nt) : 0xFFFFFFFFu;
+            continue;
+        }
         if (lane < 32) {
             uint32_t* out = a.dist + (size_t)(it.out_offset + s - a.pair_base) * MAX_FUSED_QUERY_ROWS;
             const uint32_t r0 = qt0 * 32 + (uint32_t)lane, r1 = r0 + 32;
@@ -193,6 +232,7 @@ __global__ __launch_bounds__(256, 3) void k_score_mfma_fp4(MfmaArgs a) {
         const uint32_t nt_tiles = (uint32_t)(nt + 31) / 32;
         const uint4* tb = reinterpret_cast<const uint4*>(a.db_pm1 + (size_t)slot * a.db_tiles_per_frame * FP4_TILE_BYTES);
         float best[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+        uint32_t bt[4] = {0, 0, 0, 0};                           // first tile that reached best[q] (argmin form)
         if (nt_tiles > 0) {
             uint4 g = tb[tid];
             atile[0][tid] = g;
@@ -210,13 +250,32 @@ __global__ __launch_bounds__(256, 3) void k_score_mfma_fp4(MfmaArgs a) {
                         acc[q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b[q][ks], acc[q], 4, 4, 0, SCALE_ONE, 0, SCALE_ONE);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) best[q] = fmaxf(best[q], max16f(acc[q]));
+                for (int q = 0; q < 4; ++q) {
+                    const float mq = max16f(acc[q]);
+                    if (mq > best[q]) { best[q] = mq; bt[q] = t; }      // strict: the FIRST tile keeps the title
+                }
                 if (t + 1 < nt_tiles) atile[cur ^ 1][tid] = g;
                 __syncthreads();
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) best[q] = fmaxf(best[q], __shfl_xor(best[q], 32, 64));
+        for (int q = 0; q < 4; ++q) {
+            const float ob = __shfl_xor(best[q], 32, 64);
+            const uint32_t ot = (uint32_t)__shfl_xor((int)bt[q], 32, 64);
+            if (ob > best[q] || (ob == best[q] && ot < bt[q])) { best[q] = ob; bt[q] = ot; }
+        }
+        if (a.argmin) {
+            // lanes 0-31 finish query tiles 0 and 1 of this wave, lanes 32-63 tiles 2 and 3
+            uint32_t* out = a.dist + (size_t)(it.out_offset + s - a.pair_base) * MAX_FUSED_QUERY_ROWS;
+            const uint32_t half = (uint32_t)lane >> 5, l31 = (uint32_t)lane & 31u;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t tb_ = half ? bt[2 + k] : bt[k];
+                const uint32_t r = (qt0 + 2u * half + (uint32_t)k) * 32 + l31;
+                if (r < (uint32_t)nq) out[r] = nt > 0 ? rescan_tile(a, it.q_frame, r, slot, tb_, nt) : 0xFFFFFFFFu;
+            }
+            continue;
+        }
         if (lane < 32) {
             uint32_t* out = a.dist + (size_t)(it.out_offset + s - a.pair_base) * MAX_FUSED_QUERY_ROWS;
 #pragma unroll

@@ -127,7 +127,8 @@ int mfma_online(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int pitch_rows
 }
 
 int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int32_t* d_q_counts, uint32_t q_pitch_rows,
-                     const uint32_t* q_frame_of, const int* nqv, int n_q, const std::vector<size_t>& offsets, lcm_score* d_scores) {
+                     const uint32_t* q_frame_of, const int* nqv, int n_q, const std::vector<size_t>& offsets, lcm_score* d_scores,
+                     uint32_t* d_idx_sums) {
     const bool fp4 = (h->variant == 5);                  // 4: int8 operands, 256 query rows per workgroup; 5: fp4, 512
     const size_t tile_bytes = fp4 ? lcm::FP4_TILE_BYTES : lcm::PM1_TILE_BYTES;
     const int wg_rows = fp4 ? 512 : 256;
@@ -187,6 +188,11 @@ int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int32_t* d_
             a.db_pm1 = h->d_pm1; a.db_tiles_per_frame = db_tiles; a.db_counts = h->d_counts;
             a.items = reinterpret_cast<const lcm::MfmaItem*>(h->d_mitems);
             a.dist = h->d_mdist; a.pair_base = (uint32_t)offsets[(size_t)c0];
+            if (d_idx_sums) {           // argmin form: keys out of the kernel (tile of the first best + exact re-scan of that tile)
+                a.argmin = 1;
+                a.q_rows = (const uint32_t*)q_rows; a.q_stride_words = q_pitch_rows * LCM_DESC_WORDS;
+                a.db_rows = (const uint32_t*)h->d_rows; a.db_stride_words = (uint32_t)h->stride_rows * LCM_DESC_WORDS;
+            }
             hipError_t e = fp4 ? lcm::launch_score_mfma_fp4(a, (uint32_t)items.size(), h->stream)
                                : lcm::launch_score_mfma(a, (uint32_t)items.size(), h->stream);
             if (e != hipSuccess) return fail(LCM_ERR_HIP, "MFMA kernel launch failed: %s", hipGetErrorString(e));
@@ -194,6 +200,7 @@ int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int32_t* d_
             f.dist = h->d_mdist; f.offsets = h->d_mmeta; f.nq = reinterpret_cast<const int32_t*>(h->d_mmeta + n_q + 1);
             f.db_counts = h->d_counts; f.scores = d_scores; f.n_q = (uint32_t)n_q; f.pair_base = (uint32_t)offsets[(size_t)c0];
             f.ratio = h->params.ratio; f.dist_floor = h->params.dist_floor;
+            if (d_idx_sums) { f.key_shift = lcm::KEY_SHIFT; f.idx_sums = d_idx_sums; }
             e = lcm::launch_finalize_bulk(f, (uint32_t)pairs, h->stream);
             if (e != hipSuccess) return fail(LCM_ERR_HIP, "fold kernel launch failed: %s", hipGetErrorString(e));
             launches += 2; biggest = std::max(biggest, (uint32_t)items.size());

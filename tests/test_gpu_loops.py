@@ -561,6 +561,19 @@ def test_matrix_core_variant_is_bit_exact(matcher, oracle, pkg, n_frames, max_de
         got, offs = gpu_all_vs_all(matcher)
         np.testing.assert_array_equal(offs.astype(np.int64), woffs)
         np.testing.assert_array_equal(got, want)
+        # the argmin form on the matrix cores: first tile that reaches the best dot product + exact re-scan of that tile
+        n = len(want)
+        pq = [c for c in range(n_frames) for _ in range(int(woffs[c + 1] - woffs[c]))]
+        pt = [t for c in range(n_frames) for t in range(int(woffs[c + 1] - woffs[c]))]
+        _, wsums = oracle.fast_score_pairs_idx(fs.rows, fs.counts, pq, pt, p, n_threads=8)
+        d, ds = matcher.dev_alloc(n * 8), matcher.dev_alloc(n * 4)
+        got_a, sums = np.zeros(n, want.dtype), np.zeros(n, np.uint32)
+        matcher.all_vs_all_argmin(d, n, ds)
+        assert matcher.launch_info().route == pkg.capi.ROUTE_MATRIX
+        matcher.sync(); matcher.dev_download(d, got_a); matcher.dev_download(ds, sums)
+        matcher.dev_free(d); matcher.dev_free(ds)
+        np.testing.assert_array_equal(got_a, want)
+        np.testing.assert_array_equal(sums, wsums)
         matcher.dev_upload(d_rows, fs.rows); matcher.dev_upload(d_counts, fs.counts)
         got2, _ = gpu_all_vs_all(matcher, q_ids=fs.ids, d_rows=d_rows, d_counts=d_counts, stride=fs.stride_rows)
         np.testing.assert_array_equal(got2, want)
