@@ -424,16 +424,18 @@ static int db_load_impl(lcm_handle* h, const char* path) {
     if (hd.n_frames && fread(metas.data(), sizeof(FrameMeta), hd.n_frames, f) != hd.n_frames)
         return fail(LCM_ERR_INVALID_ARG, "%s is truncated", path);
     uint64_t need = sizeof hd + (uint64_t)hd.n_frames * sizeof(FrameMeta);
+    uint32_t real_max_rows = 0;          // the arena is sized from the frames themselves, not from the header's claim
     for (size_t s = 0; s < metas.size(); ++s) {
         if (metas[s].n < 0 || (uint32_t)metas[s].n > hd.max_rows) return fail(LCM_ERR_INVALID_ARG, "%s: bad row count in frame %zu", path, s);
         if (s > 0 && metas[s].id <= metas[s - 1].id) return fail(LCM_ERR_INVALID_ARG, "%s: frame ids are not increasing", path);
         need += (uint64_t)metas[s].n * LCM_DESC_BYTES;
+        real_max_rows = std::max(real_max_rows, (uint32_t)metas[s].n);
     }
     if (need > file_bytes) return fail(LCM_ERR_INVALID_ARG, "%s is truncated (%llu bytes, needs %llu)", path,
                                        (unsigned long long)file_bytes, (unsigned long long)need);
     int rc = lcm_db_clear(h); if (rc) return rc;
-    rc = lcm_db_reserve(h, (int)hd.n_frames, (int)std::max<uint32_t>(hd.max_rows, 1));
-    std::vector<uint8_t> buf((size_t)hd.max_rows * LCM_DESC_BYTES + 1);
+    rc = lcm_db_reserve(h, (int)hd.n_frames, (int)std::max<uint32_t>(real_max_rows, 1));
+    std::vector<uint8_t> buf((size_t)real_max_rows * LCM_DESC_BYTES + 1);
     for (size_t s = 0; !rc && s < metas.size(); ++s) {
         if (metas[s].n && fread(buf.data(), LCM_DESC_BYTES, (size_t)metas[s].n, f) != (size_t)metas[s].n) { rc = fail(LCM_ERR_INVALID_ARG, "%s: read error", path); break; }
         rc = lcm_db_append(h, metas[s].id, buf.data(), metas[s].n, metas[s].n_kp);
