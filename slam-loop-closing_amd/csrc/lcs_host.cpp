@@ -11,6 +11,8 @@
 
 #include "../../include/lcm_host.h"
 
+namespace lcm { void set_last_error(const char* msg); }
+
 namespace loop_closing {
 
 namespace {
@@ -67,11 +69,45 @@ void LoopClosingSystem::processFrame(const uint8_t* descriptors, int rows, int n
     try {
         // consecutive-frame matching (README.md:96-97): previous frame = query, current = train, as the tree's own
         // incremental loop orders them (src/main.cpp:1154 matchFeatures(lastKF, cur)); pose / triangulation are out of scope
+        // One device: the loop-closure query is SUBMITTED first (asynchronous, on its query slot's own stream), the pair
+        // match then runs on the handle's stream beside it, and the records are collected afterwards — the two steps
+        // of README.md:96-100 overlap on the device instead of queueing.  A group scores synchronously.
+        const Frame& cur = frames_.back();
+        const size_t cur_pos = frames_.size() - 1;
+        static const uint8_t dummy[32] = {0};
+        int ticket = -1;
+        if (!group_ && lcm_query_submit(matcher_, cur.rows() > 0 ? cur.descriptors.data() : dummy, cur.rows(), keyOf(cur_pos), &ticket) != LCM_OK)
+            raise("processFrame: lcm_query_submit");
         consecutive_matches_.clear();
-        if (frames_.size() >= 2) consecutive_matches_ = matchFeatures(frames_[frames_.size() - 2], frames_.back());
+        try {
+            if (frames_.size() >= 2) consecutive_matches_ = matchFeatures(frames_[frames_.size() - 2], frames_.back());
+        } catch (...) {
+            if (ticket >= 0) {                                   // drain the query that is in flight, keep the first error
+                std::vector<lcm_score> sink((size_t)std::max(lcm_db_size(matcher_), 1));
+                int n = 0;
+                const std::string why = lcm_last_error();
+                (void)lcm_query_collect(matcher_, ticket, sink.data(), nullptr, (int)sink.size(), &n);
+                lcm::set_last_error(why.c_str());
+            }
+            throw;
+        }
         // loop-closure check against the frames stored so far (the current frame is the query, README.md:100,122) ...
-        std::vector<LoopCandidate> found = detectLoops(frame_id);
-        loop_closures_.insert(loop_closures_.end(), found.begin(), found.end());
+        if (group_) {
+            std::vector<LoopCandidate> found = detectLoops(frame_id);
+            loop_closures_.insert(loop_closures_.end(), found.begin(), found.end());
+        } else {
+            std::vector<lcm_score> sc((size_t)std::max(lcm_db_size(matcher_), 1));
+            int n = 0;
+            if (lcm_query_collect(matcher_, ticket, sc.data(), nullptr, (int)sc.size(), &n) != LCM_OK) raise("processFrame: lcm_query_collect");
+            lcm_params p;
+            if (lcm_get_params(matcher_, &p) != LCM_OK) raise("processFrame: lcm_get_params");
+            for (int k = 0; k < n; ++k) {                        // record k = the k-th stored frame this rank owns
+                const Frame& past = frames_[(size_t)shard_rank_ + (size_t)k * (size_t)shard_world_];
+                double sim = 0.0;
+                if (lcm_loop_test(&p, &sc[(size_t)k], cur.num_keypoints, past.num_keypoints, &sim))
+                    loop_closures_.push_back({cur.id, past.id, (int)sc[(size_t)k].good_count, sim});
+            }
+        }
         // ... then the frame joins the device database if this rank owns its position
         const size_t pos = frames_.size() - 1;
         const Frame& s = frames_.back();
