@@ -341,8 +341,11 @@ LCM_API int  lcm_merge_shard_scores_device(lcm_handle* h, const void* d_gathered
  *                         1536-row workgroups (6 rows per lane at 8 waves per SIMD: an A/B, within 0.5 % of 1)
  *   LCM_TUNE_ONLINE_STREAMS 1 (default) = each of the 4 query slots enqueues on its own stream, so consecutive online
  *                         queries overlap (upload and first workgroups of one under the draining tail of the other);
- *                         0 = everything on the handle's stream */
-typedef enum lcm_tuning { LCM_TUNE_ITEM_SLOTS = 0, LCM_TUNE_ONLINE_SPLIT = 1, LCM_TUNE_PACKED = 2, LCM_TUNE_ONLINE_STREAMS = 3 } lcm_tuning;
+ *                         0 = everything on the handle's stream
+ *   LCM_TUNE_PACKED_SCRATCH_MB  packed route: MiB of per-row scratch per chunk (default 8192; a search larger than one
+ *                         chunk runs chunk after chunk; halved by itself, down to 64, when the allocation fails) */
+typedef enum lcm_tuning { LCM_TUNE_ITEM_SLOTS = 0, LCM_TUNE_ONLINE_SPLIT = 1, LCM_TUNE_PACKED = 2, LCM_TUNE_ONLINE_STREAMS = 3,
+                          LCM_TUNE_PACKED_SCRATCH_MB = 4 } lcm_tuning;
 LCM_API int  lcm_set_tuning(lcm_handle* h, int knob, int value);
 
 /* Device scratch helpers so a host program needs no other allocator (plain hipMalloc/hipFree/hipMemcpy). */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCM_LIB_PATH") or os.path.join(_HERE, "lib", "liblcm_hip.so")
 DESC_BYTES = 32
 KEY_SHIFT = 22
-TUNE_ITEM_SLOTS, TUNE_ONLINE_SPLIT, TUNE_PACKED, TUNE_ONLINE_STREAMS = 0, 1, 2, 3      # lcm_tuning
+TUNE_ITEM_SLOTS, TUNE_ONLINE_SPLIT, TUNE_PACKED, TUNE_ONLINE_STREAMS, TUNE_PACKED_SCRATCH_MB = 0, 1, 2, 3, 4      # lcm_tuning
 
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_ORDER, ERR_NOT_FOUND, ERR_OOM = 0, -1, -2, -3, -4, -5, -6, -7   # lcm_status

@@ -287,6 +287,9 @@ int lcm_set_tuning(lcm_handle* h, int knob, int value) {
         case LCM_TUNE_ONLINE_STREAMS:
             if (value != 0 && value != 1) return fail(LCM_ERR_INVALID_ARG, "online streams must be 0 (the handle's stream) or 1 (one per query slot)");
             h->tune_online_streams = value; return LCM_OK;
+        case LCM_TUNE_PACKED_SCRATCH_MB:
+            if (value < 1 || value > 65536) return fail(LCM_ERR_INVALID_ARG, "packed scratch must be 1 .. 65536 MiB per chunk");
+            h->pk_scratch_words = (size_t)value << 18; h->plan.key = 0; return LCM_OK;
         case LCM_TUNE_PACKED:
             if (value < -1 || value > 2) return fail(LCM_ERR_INVALID_ARG, "packed rows must be -1 (automatic), 0 (off), 1 (on) or 2 (on, 1536-row columns)");
             h->tune_packed = value; h->plan.key = 0; return LCM_OK;

@@ -16,8 +16,8 @@ struct PackedPlan {
 };
 
 int build_packed_plan(const std::vector<size_t>& offsets, const std::vector<int32_t>& qn, const uint32_t* q_frame_of, int chunk,
-                      uint32_t COL, uint32_t stride, PackedPlan& pk) {
-    const size_t PK_CHUNK_PAIRS = std::max<size_t>(1, ((size_t)1 << 31) / stride);      // 8 GiB of scratch words per chunk
+                      uint32_t COL, uint32_t stride, size_t scratch_words, PackedPlan& pk) {
+    const size_t PK_CHUNK_PAIRS = std::max<size_t>(1, scratch_words / stride);      // per-row scratch of one chunk (default 8 GiB)
     const int n_q = (int)qn.size();
     auto elig_of = [&](int c) { return (uint32_t)(offsets[(size_t)c + 1] - offsets[(size_t)c]); };
     pk.tab.resize((size_t)n_q * 2 + 1);
@@ -150,6 +150,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     key = mix(mix(key, self ? 1 : 2), (uint64_t)q_stride_rows);
     key = mix(key, h->db_generation);
     key = mix(key, pack_ok ? 0x9Bull + (uint64_t)(h->tune_packed + 1) : 0x9Aull);
+    key = mix(key, (uint64_t)h->pk_scratch_words);
     for (int i = 0; i < n_q_frames; ++i) key = mix(key, (uint64_t)(uint32_t)q_ids[i]);
     if (q_frame_of) for (int i = 0; i < n_q_frames; ++i) key = mix(key, 0x51ull + q_frame_of[i]);
     for (int32_t c : qc) key = mix(key, (uint64_t)(uint32_t)c);
@@ -193,7 +194,7 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
             P.pk_col_rows = h->tune_packed == 2 ? 1536u : (uint32_t)lcm::MAX_FUSED_QUERY_ROWS;
             // scratch words per pair: 2048, or the largest query frame (rounded up) when frames exceed that
             P.pk_stride = big_rows ? (uint32_t)round_up(P.max_q_rows, 256) : (uint32_t)lcm::MAX_FUSED_QUERY_ROWS;
-            rc = build_packed_plan(P.offsets, qn, q_frame_of, chunk, P.pk_col_rows, P.pk_stride, pk); if (rc) return rc;
+            rc = build_packed_plan(P.offsets, qn, q_frame_of, chunk, P.pk_col_rows, P.pk_stride, h->pk_scratch_words, pk); if (rc) return rc;
             const uint64_t shape_rows = P.max_q_rows <= 512 ? 512 : P.max_q_rows <= 1024 ? 1024 : P.max_q_rows <= 1536 ? 1536 : 2048;
             const uint64_t lanes_plain = (uint64_t)total * shape_rows;
             // automatic: worth it when it saves >= 1 % of the lane slots of a search big enough to be throughput-bound
@@ -270,7 +271,19 @@ static int all_vs_all_impl(lcm_handle* h, const void* d_query_rows, const int32_
     a.idx_sums = d_idx_sums;             // non-NULL: the argmin kernel (variant 1) runs whatever the handle's variant
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
     const int variant = d_idx_sums ? 1 : h->variant;
-    if (P.packed) return launch_packed(h, P, a, variant == 1, d_scores, d_idx_sums);
+    if (P.packed) {
+        rc = launch_packed(h, P, a, variant == 1, d_scores, d_idx_sums);
+        // The per-row scratch (8 GiB per chunk by default) did not fit next to whatever else lives on this device: halve the
+        // chunk and plan again, down to 64 MiB, rather than fail a search whose inputs and outputs do fit.
+        if (rc == LCM_ERR_OOM && h->pk_scratch_words > ((size_t)1 << 24)) {
+            (void)hipGetLastError();                 // the failed allocation's sticky error must not be read as a launch failure
+            h->pk_scratch_words >>= 1;
+            P.key = 0;
+            return all_vs_all_impl(h, d_query_rows, d_query_counts, self ? nullptr : q_ids, n_q_frames, q_stride_rows, d_scores, scores_cap,
+                                   n_pairs, pair_offsets, d_idx_sums, q_frame_of, h_query_counts);
+        }
+        return rc;
+    }
     // Very large searches go out as several launches (<= 2^20 work items, a few seconds each): no single kernel runs
     // long enough to meet a compute-queue timeout, and the stream stays responsive.
     constexpr size_t MAX_ITEMS_PER_LAUNCH = 1u << 20;

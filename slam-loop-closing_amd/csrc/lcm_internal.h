@@ -141,6 +141,7 @@ struct lcm_handle {
     int tune_item_slots = 0;           // 0 = automatic (pick_chunk)
     int tune_online_split = -1;        // -1 = automatic (enqueue_query)
     int tune_online_streams = 1;       // 1 = every query slot runs on its own stream, 0 = all on the handle's stream
+    size_t pk_scratch_words = (size_t)1 << 31;   // packed route: words of per-row scratch per chunk (halved after an OOM)
     int tune_packed = -1;              // -1 = automatic (bulk plan: when it saves lane slots), 0 = never, 1 = always
 
     // database arena

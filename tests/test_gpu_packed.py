@@ -181,6 +181,7 @@ def test_packed_equals_plain_on_random_shapes(matcher, oracle, pkg, seed):
     gap = int(rng.integers(0, 6))
     matcher.set_params(min_gap=gap)
     matcher.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, int(rng.choice([0, 1, 3, 8])))
+    matcher.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, int(rng.choice([1, 2, 16, 8192])))     # 1 MiB: 128 pairs per chunk -> many chunks
     try:
         matcher.clear()
         for f in range(n_frames):
@@ -208,6 +209,7 @@ def test_packed_equals_plain_on_random_shapes(matcher, oracle, pkg, seed):
         np.testing.assert_array_equal(res[1][1][k], wsums)
     finally:
         matcher.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, 0)
+        matcher.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, 8192)
         matcher.set_tuning(pkg.capi.TUNE_PACKED, -1)
         matcher.set_params(min_gap=30)
         matcher.clear()
