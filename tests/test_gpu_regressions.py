@@ -186,3 +186,37 @@ def test_snapshot_loader_survives_random_corruption(pkg, oracle, tmp_path):
         assert len(m) == fs.n_frames
         for s in (0, 5, 11):
             np.testing.assert_array_equal(m.read_frame(s), fs.frame(s))
+
+
+def test_packed_route_shrinks_its_scratch_when_the_device_is_full(pkg, oracle):
+    """The packed route's per-row scratch (3.9 GB for this search) does not fit next to a ballast that leaves ~2 GiB free:
+    the library halves its chunk size and plans again (LCM_ERR_OOM never reaches the caller), the records are the same."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no device visible to torch")
+    fs = pkg.synth.make_frames(1000, 2000, seed=pkg.synth.BASE_SEED + 2)
+    p = pkg.default_params()
+    p.min_gap = 30
+    with pkg.Matcher(p) as m:
+        m.reserve(fs.n_frames, 2000)
+        for f in range(fs.n_frames):
+            m.append(int(fs.ids[f]), fs.frame(f))
+        n, offs = m.all_vs_all_plan()
+        d = m.dev_alloc(n * 8)
+        ref = np.zeros(n, pkg.capi.SCORE_DTYPE)
+        m.set_tuning(pkg.capi.TUNE_PACKED, 0)
+        m.all_vs_all(d, n); m.sync(); m.dev_download(d, ref)                 # plain route: no scratch
+        m.set_tuning(pkg.capi.TUNE_PACKED, 1)
+        free, _total = torch.cuda.mem_get_info(0)
+        ballast = None
+        try:
+            ballast = torch.empty(max(free - (2 << 30), 0), dtype=torch.uint8, device="cuda:0")
+            got = np.zeros(n, pkg.capi.SCORE_DTYPE)
+            m.all_vs_all(d, n); m.sync(); m.dev_download(d, got)
+            info = m.launch_info()
+        finally:
+            del ballast
+            torch.cuda.empty_cache()
+        np.testing.assert_array_equal(got, ref)
+        assert info.route == pkg.capi.ROUTE_PACKED and info.launches >= 4      # several (score, fold) chunks now
+        m.dev_free(d)
