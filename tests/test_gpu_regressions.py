@@ -210,7 +210,10 @@ def test_packed_route_shrinks_its_scratch_when_the_device_is_full(pkg, oracle):
         free, _total = torch.cuda.mem_get_info(0)
         ballast = None
         try:
-            ballast = torch.empty(max(free - (2 << 30), 0), dtype=torch.uint8, device="cuda:0")
+            try:
+                ballast = torch.empty(max(free - (2 << 30), 0), dtype=torch.uint8, device="cuda:0")
+            except RuntimeError:
+                pytest.skip("could not fill the device (someone else holds memory)")
             got = np.zeros(n, pkg.capi.SCORE_DTYPE)
             m.all_vs_all(d, n); m.sync(); m.dev_download(d, got)
             info = m.launch_info()
