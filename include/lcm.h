@@ -144,8 +144,11 @@ LCM_API const char* lcm_last_error(void);
 LCM_API const char* lcm_backend_name(void);         /* "hip-gfx950" */
 LCM_API int         lcm_device_count(void);         /* #HIP devices, 0 if none / no runtime */
 
-/* Create a matcher bound to HIP device `device_id`.  `stream` is a hipStream_t (as void*) that all work is
- * enqueued on, or NULL for a library-owned stream. */
+/* Create a matcher bound to HIP device `device_id`.  `stream` is a hipStream_t (as void*) that the bulk, pair-mode
+ * and database work is enqueued on, or NULL for a library-owned stream.  Online queries (lcm_query_submit*,
+ * lcm_detect_loops) run on streams the library owns, one per query slot, each ordered AFTER everything `stream` and the
+ * append path already hold at submit time; their results reach the caller through the collect calls only, so nothing
+ * on `stream` has to wait for them (LCM_TUNE_ONLINE_STREAMS = 0 puts them back on `stream`). */
 LCM_API int  lcm_create(const lcm_params* params, int device_id, void* stream, lcm_handle** out);
 LCM_API void lcm_destroy(lcm_handle* h);
 LCM_API int  lcm_set_params(lcm_handle* h, const lcm_params* params);
