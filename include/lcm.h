@@ -111,7 +111,10 @@ typedef struct lcm_loop_candidate {
     double  similarity_score;
 } lcm_loop_candidate;
 
-/* Timing of the most recent bulk launch on this handle, from hipEvents on the launch stream. */
+/* Timing of the most recent bulk / pair-mode launch on this handle, from hipEvents on the launch stream.  Meant for
+ * the bulk calls: online queries record into the same events from their own streams, so while online tickets are
+ * outstanding (or a processFrame-style pair match runs beside one) the structure describes whichever launch recorded
+ * last and is not attributable to a call — read lcm_online_stats_read for online work. */
 typedef struct lcm_launch_info {
     double   kernel_ms;         /* device time of the pair-match kernel(s) of the last bulk call */
     uint64_t pairs;             /* (query frame, stored frame) pairs scored */
@@ -119,9 +122,17 @@ typedef struct lcm_launch_info {
     uint64_t algo_bytes;        /* sum n_train*32 per pair + n_query*32 per query frame + 8 per pair */
     uint32_t launches;          /* kernel launches that made up the call */
     uint32_t workgroups;        /* workgroups of the (largest) launch */
-    double   aux_kernel_ms;     /* device time of the call's follow-up kernel, 0 if none: k_loop_test of
-                                 * lcm_all_vs_all_loops; the (last chunk's) fold kernel of a packed bulk search */
+    double   aux_kernel_ms;     /* device time of the call's follow-up kernels, 0 if none: the loop-test kernels
+                                 * (k_loop_count, k_block_scan, k_loop_emit and the count read-back between them) of
+                                 * lcm_all_vs_all_loops; the fold kernels of a packed bulk search (summed over its chunks:
+                                 * kernel_ms - aux_kernel_ms is then the score kernels' time) */
     uint32_t route;             /* which kernels served the call: lcm_route */
+    uint32_t launches_in_flight; /* packed bulk search of several chunks: 2 (consecutive chunks run on two streams, so that one
+                                 * chunk's workgroups fill the chip while the other's launch drains); else 1 */
+    double   score_ms_sum;      /* packed bulk search: SUM of the score kernels' own durations, each from events around it on
+                                 * its stream (what a kernel trace reports per launch).  With 2 launches in flight they
+                                 * overlap pairwise: score_ms_sum ~ launches_in_flight x (kernel_ms - exposed folds) */
+    uint32_t score_launches;    /* packed bulk search: number of score launches (= chunks) */
     uint32_t reserved_;
 } lcm_launch_info;
 /* LCM_ROUTE_PLAIN: one workgroup per (query frame, run of stored frames), records formed in the kernel;
@@ -166,6 +177,9 @@ LCM_API int  lcm_db_append(lcm_handle* h, int frame_id, const uint8_t* desc, int
 LCM_API int  lcm_db_append_device(lcm_handle* h, int frame_id, const void* d_desc, int n, int n_keypoints);
 LCM_API int  lcm_db_size(const lcm_handle* h);                 /* frames stored */
 LCM_API int  lcm_db_clear(lcm_handle* h);
+/* Keep the first n_frames stored frames, drop the rest (no-op if fewer are stored).  Waits for everything in flight;
+ * tickets submitted before the call are void afterwards, as after lcm_db_clear. */
+LCM_API int  lcm_db_truncate(lcm_handle* h, int n_frames);
 LCM_API int  lcm_db_frame_info(const lcm_handle* h, int slot, int* frame_id, int* n_desc, int* n_keypoints);
 /* Copy a stored frame's rows back to the host (tests / snapshot). */
 LCM_API int  lcm_db_read(lcm_handle* h, int slot, uint8_t* desc_out, int cap_rows);
@@ -286,12 +300,19 @@ LCM_API int  lcm_set_kernel_variant(lcm_handle* h, int variant);
 typedef struct lcm_group lcm_group;
 typedef struct lcm_group_info {
     int32_t  n_devices;
+    int32_t  rccl_ranks;                     /* ncclCommCount of the group's communicator; 0 for a loopback rehearsal group */
     uint64_t pairs, distances, algo_bytes;   /* summed over the shards */
     double   kernel_ms_max;                  /* slowest shard's scoring kernel(s) */
     double   gather_merge_ms;                /* first device: its kernel's end -> records gathered (RCCL) and merged */
     double   download_ms;                    /* merged array -> host */
-    uint64_t gathered_query_bytes;           /* per device: bytes received by the all-gather of the shard arenas */
-    uint64_t gathered_score_bytes;           /* bytes of score records that crossed xGMI to the first device */
+    uint64_t gathered_query_bytes;           /* per device: bytes received by THIS call's all-gather of the shard arenas
+                                              * (0 when it was skipped: nothing appended since the last search) */
+    uint64_t gathered_score_bytes;           /* bytes of score records (+ index checksums) that crossed xGMI to the first device */
+    double   allgather_ms;                   /* first device: duration of the arena all-gather (0 when skipped) */
+    double   kernel_ms[8];                   /* per device: its shard's scoring kernel(s) */
+    uint64_t shard_pairs[8];                 /* per device: pairs its shard scored */
+    int32_t  arena_gather_skipped;           /* 1: the gathered query buffers of the previous search were reused */
+    int32_t  loopback;                       /* 1: rehearsal group (all shards on one device, no RCCL) */
 } lcm_group_info;
 /* device_ids == NULL: devices 0 .. n_devices-1.  n_devices <= 8. */
 LCM_API int  lcm_group_create(const lcm_params* params, int n_devices, const int* device_ids, lcm_group** out);
@@ -307,9 +328,25 @@ LCM_API int  lcm_group_set_params(lcm_group* g, const lcm_params* params);
 LCM_API int  lcm_group_reserve(lcm_group* g, int n_frames, int max_desc);
 LCM_API int  lcm_group_append(lcm_group* g, int frame_id, const uint8_t* desc, int n, int n_keypoints);
 LCM_API int  lcm_group_clear(lcm_group* g);
+/* Keep the first n_frames frames (arrival order), drop the rest; tickets in flight become void (lcm_db_truncate per shard). */
+LCM_API int  lcm_group_truncate(lcm_group* g, int n_frames);
+LCM_API int  lcm_group_sync(lcm_group* g);                                   /* lcm_sync on every shard */
+LCM_API int  lcm_group_set_tuning(lcm_group* g, int knob, int value);        /* lcm_set_tuning on every shard */
+LCM_API int  lcm_group_set_kernel_variant(lcm_group* g, int variant);        /* lcm_set_kernel_variant on every shard */
 /* out_scores (host) receives *n_pairs records in (query ascending, stored ascending) order; pair_offsets (host,
- * optional, db_size + 1 entries); out_scores == NULL sizes only. */
+ * optional, db_size + 1 entries); out_scores == NULL sizes only.  The all-gather of the shard arenas is skipped when
+ * nothing was appended since the previous search (lcm_group_info.arena_gather_skipped). */
 LCM_API int  lcm_group_all_vs_all(lcm_group* g, lcm_score* out_scores, size_t cap, size_t* n_pairs, size_t* pair_offsets);
+/* lcm_all_vs_all_argmin over the group: the same search through the ARGMIN kernel; out_index_sums (host, one uint32 per
+ * pair, same order) receives the per-pair index checksums, gathered and merged like the records.  A group of ONE device
+ * returns byte for byte what lcm_all_vs_all_argmin writes on a single handle. */
+LCM_API int  lcm_group_all_vs_all_argmin(lcm_group* g, lcm_score* out_scores, uint32_t* out_index_sums, size_t cap,
+                                         size_t* n_pairs, size_t* pair_offsets);
+/* lcm_all_vs_all_loops over the group (BASELINE.json configs[3] on several devices): every device scores its shard and
+ * applies the loop test to its own records ON THE DEVICE; only the candidates leave the devices — each shard's over its
+ * own PCIe link, all links at once — and are merged on the host into (current id, matched id) order.  *n_out = number
+ * found (LCM_ERR_CAPACITY if > cap, nothing written); *n_pairs_out (optional) = pairs scored. */
+LCM_API int  lcm_group_all_vs_all_loops(lcm_group* g, lcm_loop_candidate* out, size_t cap, size_t* n_out, size_t* n_pairs_out);
 LCM_API int  lcm_group_last_info(const lcm_group* g, lcm_group_info* info);
 /* lcm_query_scores / lcm_detect_loops over all shards (query uploaded to every device; per-shard records interleaved
  * on the host: a few KB per query). */
@@ -320,6 +357,17 @@ LCM_API int  lcm_group_query_scores(lcm_group* g, const uint8_t* query, int nq, 
 LCM_API int  lcm_group_query_scores_batch(lcm_group* g, const uint8_t* const* queries, const int* nq,
                                           const int* query_frame_ids, int n_queries,
                                           lcm_score* out_scores, size_t cap, size_t* n_out, size_t* offsets);
+/* The asynchronous form (what keeps W devices busy in streaming mode): submit returns once every device has the batch
+ * ENQUEUED — each from its own host thread; the callers' buffers are free then — with one group ticket; up to 4 may be in
+ * flight (submit batch k + 1, append, then collect batch k).  Collect waits for that ticket; every device's thread writes
+ * its records straight into their places of the single-device order.  A too-small `cap` keeps the ticket valid; a
+ * lcm_group_clear / _truncate in between voids it (LCM_ERR_NOT_FOUND). */
+LCM_API int  lcm_group_query_submit_batch(lcm_group* g, const uint8_t* const* queries, const int* nq,
+                                          const int* query_frame_ids, int n_queries, int* ticket);
+LCM_API int  lcm_group_query_collect_batch(lcm_group* g, int ticket, lcm_score* out_scores, size_t cap, size_t* n_out,
+                                           size_t* offsets);
+/* lcm_online_stats_read over the shards: work summed, kernel_ms = the slowest shard's (the devices run side by side). */
+LCM_API int  lcm_group_online_stats_read(lcm_group* g, lcm_online_stats* out, int reset);
 LCM_API int  lcm_group_detect_loops(lcm_group* g, int current_frame_id, const uint8_t* query, int nq, int n_keypoints,
                                     lcm_loop_candidate* out, int cap, int* n_out);
 /* Host-only (no device needed): merge W per-shard score arrays — shard r in (query ascending, owned stored ascending)
@@ -345,8 +393,12 @@ LCM_API int  lcm_merge_shard_scores_device(lcm_handle* h, const void* d_gathered
  *   LCM_TUNE_ONLINE_STREAMS 1 (default) = each of the 4 query slots enqueues on its own stream, so consecutive online
  *                         queries overlap (upload and first workgroups of one under the draining tail of the other);
  *                         0 = everything on the handle's stream
- *   LCM_TUNE_PACKED_SCRATCH_MB  packed route: MiB of per-row scratch per chunk (default 8192; a search larger than one
- *                         chunk runs chunk after chunk; halved by itself, down to 64, when the allocation fails) */
+ *   LCM_TUNE_PACKED_SCRATCH_MB  packed route: MiB of per-row scratch per chunk (default 1024; a search larger than one
+ *                         chunk runs chunk after chunk; halved for the search at hand, down to 64, when the allocation
+ *                         fails — the next plan starts from the configured size again).  Device footprint of a handle
+ *                         beyond its database: this scratch (allocated at the first packed search, given back when a
+ *                         later search needs less than a quarter of it), 8 bytes per pair of the fused loop search's
+ *                         score array, and the staging of up to 4 online queries. */
 typedef enum lcm_tuning { LCM_TUNE_ITEM_SLOTS = 0, LCM_TUNE_ONLINE_SPLIT = 1, LCM_TUNE_PACKED = 2, LCM_TUNE_ONLINE_STREAMS = 3,
                           LCM_TUNE_PACKED_SCRATCH_MB = 4 } lcm_tuning;
 LCM_API int  lcm_set_tuning(lcm_handle* h, int knob, int value);

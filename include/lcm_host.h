@@ -21,6 +21,11 @@ typedef struct lcs_system lcs_system;
  * (1-GPU: 0 / 1). */
 LCM_API int  lcs_create(double loop_threshold, int min_loop_gap, int device_id, int shard_rank, int shard_world,
                         lcs_system** out);
+/* The multi-device constructor (loop_closing_system.hpp): the same system over n_devices MI355X of one node behind an
+ * lcm_group (device_ids == NULL: 0 .. n_devices-1).  loopback_device >= 0: rehearsal form — n_devices shards on that one
+ * device (lcm_group_create_loopback); pass -1 for real devices. */
+LCM_API int  lcs_create_group(double loop_threshold, int min_loop_gap, int n_devices, const int* device_ids,
+                              int loopback_device, lcs_system** out);
 LCM_API void lcs_destroy(lcs_system* s);
 /* processFrame (include/loop_closing.hpp:34) with the ORB stage already done: `desc` is what
  * detectFeatures would have put in Frame::descriptors (rows x 32, CV_8U), n_keypoints = keypoints.size(). */

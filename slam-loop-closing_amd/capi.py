@@ -51,7 +51,8 @@ class LoopCandidate(C.Structure):
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("pairs", C.c_uint64), ("distances", C.c_uint64),
                 ("algo_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32),
-                ("aux_kernel_ms", C.c_double), ("route", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("aux_kernel_ms", C.c_double), ("route", C.c_uint32), ("launches_in_flight", C.c_uint32),
+                ("score_ms_sum", C.c_double), ("score_launches", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 ROUTE_PLAIN, ROUTE_PACKED, ROUTE_SPLIT, ROUTE_MATRIX, ROUTE_CROSS = range(5)      # lcm_route
@@ -63,9 +64,11 @@ class OnlineStats(C.Structure):
 
 
 class GroupInfo(C.Structure):
-    _fields_ = [("n_devices", C.c_int32), ("pairs", C.c_uint64), ("distances", C.c_uint64), ("algo_bytes", C.c_uint64),
-                ("kernel_ms_max", C.c_double), ("gather_merge_ms", C.c_double), ("download_ms", C.c_double),
-                ("gathered_query_bytes", C.c_uint64), ("gathered_score_bytes", C.c_uint64)]
+    _fields_ = [("n_devices", C.c_int32), ("rccl_ranks", C.c_int32), ("pairs", C.c_uint64), ("distances", C.c_uint64),
+                ("algo_bytes", C.c_uint64), ("kernel_ms_max", C.c_double), ("gather_merge_ms", C.c_double),
+                ("download_ms", C.c_double), ("gathered_query_bytes", C.c_uint64), ("gathered_score_bytes", C.c_uint64),
+                ("allgather_ms", C.c_double), ("kernel_ms", C.c_double * 8), ("shard_pairs", C.c_uint64 * 8),
+                ("arena_gather_skipped", C.c_int32), ("loopback", C.c_int32)]
 
 
 SCORE_DTYPE = np.dtype([("good_count", "<u4"), ("min_dist", "<u2"), ("n_train", "<u2")])
@@ -98,6 +101,7 @@ _SIGNATURES = {
     "lcm_db_append_device": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
     "lcm_db_size": (C.c_int, [_vp]),
     "lcm_db_clear": (C.c_int, [_vp]),
+    "lcm_db_truncate": (C.c_int, [_vp, C.c_int]),
     "lcm_db_frame_info": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p]),
     "lcm_db_read": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
     "lcm_db_save": (C.c_int, [_vp, C.c_char_p]),
@@ -135,7 +139,16 @@ _SIGNATURES = {
     "lcm_group_reserve": (C.c_int, [_vp, C.c_int, C.c_int]),
     "lcm_group_append": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
     "lcm_group_clear": (C.c_int, [_vp]),
+    "lcm_group_truncate": (C.c_int, [_vp, C.c_int]),
+    "lcm_group_sync": (C.c_int, [_vp]),
+    "lcm_group_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "lcm_group_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
     "lcm_group_all_vs_all": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
+    "lcm_group_all_vs_all_argmin": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
+    "lcm_group_all_vs_all_loops": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lcm_group_query_submit_batch": (C.c_int, [_vp, _vp, _i32p, _i32p, C.c_int, _i32p]),
+    "lcm_group_query_collect_batch": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
+    "lcm_group_online_stats_read": (C.c_int, [_vp, C.POINTER(OnlineStats), C.c_int]),
     "lcm_group_last_info": (C.c_int, [_vp, C.POINTER(GroupInfo)]),
     "lcm_group_query_scores": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _i32p]),
     "lcm_group_query_scores_batch": (C.c_int, [_vp, _vp, _i32p, _i32p, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
@@ -262,6 +275,9 @@ class Matcher:
 
     def clear(self):
         _check(self._lib.lcm_db_clear(self._h))
+
+    def truncate(self, n_frames: int):
+        _check(self._lib.lcm_db_truncate(self._h, n_frames))
 
     def frame_info(self, slot: int) -> Tuple[int, int, int]:
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
@@ -590,6 +606,63 @@ class Group:
         _check(self._lib.lcm_group_all_vs_all(self._g, out.ctypes.data_as(_vp), len(out), C.byref(n), None))
         return out[: n.value], offs
 
+    def truncate(self, n_frames: int):
+        _check(self._lib.lcm_group_truncate(self._g, n_frames))
+
+    def sync(self):
+        _check(self._lib.lcm_group_sync(self._g))
+
+    def set_tuning(self, knob: int, value: int):
+        _check(self._lib.lcm_group_set_tuning(self._g, knob, value))
+
+    def set_kernel_variant(self, v: int):
+        _check(self._lib.lcm_group_set_kernel_variant(self._g, v))
+
+    def all_vs_all_argmin(self, out: Optional[np.ndarray] = None, out_idx: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(merged scores, merged per-pair index checksums, offsets[len + 1]) — lcm_group_all_vs_all_argmin.
+        `out` / `out_idx`: reusable host buffers (SCORE_DTYPE / uint32) of at least the pair count."""
+        n = C.c_size_t(0)
+        offs = np.zeros(len(self) + 1, np.uintp)
+        _check(self._lib.lcm_group_all_vs_all_argmin(self._g, None, None, 0, C.byref(n), offs.ctypes.data_as(_vp)))
+        if out is None or len(out) < n.value:
+            out = np.zeros(max(n.value, 1), SCORE_DTYPE)
+        if out_idx is None or len(out_idx) < n.value:
+            out_idx = np.zeros(max(n.value, 1), np.uint32)
+        _check(self._lib.lcm_group_all_vs_all_argmin(self._g, out.ctypes.data_as(_vp), out_idx.ctypes.data_as(_vp),
+                                                     min(len(out), len(out_idx)), C.byref(n), None))
+        return out[: n.value], out_idx[: n.value], offs
+
+    def all_vs_all_loops(self, cap: int = 1 << 20, out: Optional[np.ndarray] = None) -> Tuple[np.ndarray, int]:
+        """(loop candidates in (current, matched) order, pairs scored) — lcm_group_all_vs_all_loops."""
+        if out is None:
+            out = np.zeros(max(cap, 1), CANDIDATE_DTYPE)
+        n, npairs = C.c_size_t(0), C.c_size_t(0)
+        _check(self._lib.lcm_group_all_vs_all_loops(self._g, out.ctypes.data_as(_vp), len(out), C.byref(n), C.byref(npairs)))
+        return out[: n.value], npairs.value
+
+    def query_submit_batch(self, queries: Sequence[np.ndarray], query_frame_ids: Sequence[int]) -> int:
+        qs = [_rows(q) for q in queries]
+        B = len(qs)
+        ptrs = (_vp * B)(*[q.ctypes.data if q.shape[0] else None for q in qs])
+        nq = np.array([q.shape[0] for q in qs], np.int32)
+        ids = np.ascontiguousarray(query_frame_ids, np.int32)
+        t = C.c_int32(-1)
+        _check(self._lib.lcm_group_query_submit_batch(self._g, ptrs, nq.ctypes.data_as(_i32p), ids.ctypes.data_as(_i32p), B, C.byref(t)))
+        return t.value
+
+    def query_collect_batch(self, ticket: int, cap: int, n_queries: int = 16) -> Tuple[np.ndarray, np.ndarray]:
+        scores = np.zeros(max(cap, 1), SCORE_DTYPE)
+        offs = np.zeros(n_queries + 1, np.uintp)
+        n = C.c_size_t(0)
+        _check(self._lib.lcm_group_query_collect_batch(self._g, ticket, scores.ctypes.data_as(_vp), len(scores), C.byref(n),
+                                                       offs.ctypes.data_as(_vp)))
+        return scores[: n.value], offs
+
+    def online_stats(self, reset: bool = False) -> OnlineStats:
+        st = OnlineStats()
+        _check(self._lib.lcm_group_online_stats_read(self._g, C.byref(st), 1 if reset else 0))
+        return st
+
     def info(self) -> GroupInfo:
         gi = GroupInfo()
         _check(self._lib.lcm_group_last_info(self._g, C.byref(gi)))
@@ -635,6 +708,7 @@ class Group:
 # ---------------------------------------------------------------------------------------------------------
 _HOST_SIGNATURES = {
     "lcs_create": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lcs_create_group": (C.c_int, [C.c_double, C.c_int, C.c_int, _i32p, C.c_int, C.POINTER(_vp)]),
     "lcs_destroy": (None, [_vp]),
     "lcs_process_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     "lcs_process_frames": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int]),
@@ -655,13 +729,21 @@ class LoopClosingSystem:
     the reference class (include/loop_closing.hpp:29-80), driven through the C shim."""
 
     def __init__(self, loop_threshold: float = 0.7, min_loop_gap: int = 30, device: int = 0, shard_rank: int = 0,
-                 shard_world: int = 1):
+                 shard_world: int = 1, group_devices: Optional[Sequence[int]] = None, loopback_shards: int = 0):
+        """group_devices: the multi-device constructor (one process, an lcm_group over those devices);
+        loopback_shards > 0: its rehearsal form, that many shards on `device`."""
         self._lib = load_library()
         for name, (res, args) in _HOST_SIGNATURES.items():
             fn = getattr(self._lib, name)
             fn.restype, fn.argtypes = res, args
         self._s = _vp()
-        _check(self._lib.lcs_create(loop_threshold, min_loop_gap, device, shard_rank, shard_world, C.byref(self._s)))
+        if loopback_shards > 0:
+            _check(self._lib.lcs_create_group(loop_threshold, min_loop_gap, loopback_shards, None, device, C.byref(self._s)))
+        elif group_devices is not None:
+            ids = np.ascontiguousarray(group_devices, np.int32)
+            _check(self._lib.lcs_create_group(loop_threshold, min_loop_gap, len(ids), ids.ctypes.data_as(_i32p), -1, C.byref(self._s)))
+        else:
+            _check(self._lib.lcs_create(loop_threshold, min_loop_gap, device, shard_rank, shard_world, C.byref(self._s)))
 
     def close(self):
         if getattr(self, "_s", None):

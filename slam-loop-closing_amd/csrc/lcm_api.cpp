@@ -91,6 +91,8 @@ int grow_arena(lcm_handle* h, int need_frames, int need_rows) {
     uint8_t* nrows = nullptr;
     int32_t* ncounts = nullptr;
     size_t bytes = (size_t)new_cap * new_stride * LCM_DESC_BYTES + ARENA_SLACK;
+    // the two new buffers belong to this function until they are installed: every failure path below gives them back
+    struct Pending { uint8_t*& r; int32_t*& c; bool keep = false; ~Pending() { if (!keep) { (void)hipFree(r); (void)hipFree(c); } } } pending{nrows, ncounts};
     HIP_TRY(hipMalloc((void**)&nrows, bytes));
     HIP_TRY(hipMalloc((void**)&ncounts, sizeof(int32_t) * (size_t)new_cap));
     HIP_TRY(hipMemsetAsync(nrows, 0, bytes, h->stream));
@@ -106,8 +108,8 @@ int grow_arena(lcm_handle* h, int need_frames, int need_rows) {
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     { int rc = sync_online_streams(h); if (rc) return rc; }      // queries in flight still read the old arena
-    if (h->d_rows) HIP_TRY(hipFree(h->d_rows));
-    if (h->d_counts) HIP_TRY(hipFree(h->d_counts));
+    pending.keep = true;                                          // from here on the handle owns them
+    (void)hipFree(h->d_rows); (void)hipFree(h->d_counts);
     h->d_rows = nrows; h->d_counts = ncounts;
     h->cap_frames = new_cap; h->stride_rows = new_stride;
     h->plan.key = 0;
@@ -208,6 +210,7 @@ void lcm_destroy(lcm_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     for (QuerySlot& q : h->qslots) if (q.stream) (void)hipStreamSynchronize(q.stream);
     (void)hipFree(h->d_rows); (void)hipFree(h->d_counts);
     (void)hipFree(h->d_keys); (void)hipFree(h->plan.d_items); (void)hipFree(h->plan.d_pk_tab);
@@ -237,6 +240,10 @@ void lcm_destroy(lcm_handle* h) {
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->ev_aux_start) (void)hipEventDestroy(h->ev_aux_start);
     if (h->ev_aux_stop) (void)hipEventDestroy(h->ev_aux_stop);
+    for (hipEvent_t ev : h->fold_ev) (void)hipEventDestroy(ev);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -264,6 +271,7 @@ int lcm_sync(lcm_handle* h) {
     int rc = set_device(h); if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->copy_stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
     return sync_online_streams(h);
 }
 
@@ -289,7 +297,7 @@ int lcm_set_tuning(lcm_handle* h, int knob, int value) {
             h->tune_online_streams = value; return LCM_OK;
         case LCM_TUNE_PACKED_SCRATCH_MB:
             if (value < 1 || value > 65536) return fail(LCM_ERR_INVALID_ARG, "packed scratch must be 1 .. 65536 MiB per chunk");
-            h->pk_scratch_words = (size_t)value << 18; h->plan.key = 0; return LCM_OK;
+            h->pk_scratch_cfg_words = h->pk_scratch_words = (size_t)value << 18; h->plan.key = 0; return LCM_OK;
         case LCM_TUNE_PACKED:
             if (value < -1 || value > 2) return fail(LCM_ERR_INVALID_ARG, "packed rows must be -1 (automatic), 0 (off), 1 (on) or 2 (on, 1536-row columns)");
             h->tune_packed = value; h->plan.key = 0; return LCM_OK;
@@ -360,6 +368,16 @@ int lcm_db_clear(lcm_handle* h) {
     // Tickets of queries submitted against the dropped frames stay collectable, but only to learn that: their records
     // refer to slots that no longer exist (lcm_query_collect returns LCM_ERR_NOT_FOUND and frees the ticket).
     ++h->db_generation;
+    return LCM_OK;
+}
+
+int lcm_db_truncate(lcm_handle* h, int n_frames) {
+    if (!h || n_frames < 0) return fail(LCM_ERR_INVALID_ARG, "bad argument");
+    if ((size_t)n_frames >= h->frames.size()) return LCM_OK;
+    int rc = lcm_sync(h); if (rc) return rc;        // nothing in flight may still read the slots that go away
+    h->frames.resize((size_t)n_frames);
+    h->plan.key = 0;
+    ++h->db_generation;                             // tickets submitted against the longer database are void (as after a clear)
     return LCM_OK;
 }
 
@@ -475,6 +493,20 @@ int lcm_last_launch_info(const lcm_handle* hc, lcm_launch_info* info) {
         h->info.kernel_ms = ms;
         h->info.aux_kernel_ms = 0.0;
         h->info_pending = false;
+        h->info.score_launches = 0; h->info.score_ms_sum = 0.0;
+        if (h->info.route == LCM_ROUTE_PACKED) {          // per chunk: its score kernel, its fold kernel (ev_stop has passed: all are done)
+            double fold = 0.0, score = 0.0;
+            for (size_t k = 0; k + 3 <= h->fold_ev_used && k + 3 <= h->fold_ev.size(); k += 3) {
+                float f = 0.f;
+                if (hipEventElapsedTime(&f, h->fold_ev[k], h->fold_ev[k + 1]) == hipSuccess) score += f; else (void)hipGetLastError();
+                if (hipEventElapsedTime(&f, h->fold_ev[k + 1], h->fold_ev[k + 2]) == hipSuccess) fold += f; else (void)hipGetLastError();
+                ++h->info.score_launches;
+            }
+            h->info.aux_kernel_ms = fold;
+            h->info.score_ms_sum = score;
+        } else {
+            h->info.launches_in_flight = 1;
+        }
     }
     if (h->aux_pending) {
         HIP_TRY(hipEventSynchronize(h->ev_aux_stop));

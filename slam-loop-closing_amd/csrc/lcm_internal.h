@@ -99,8 +99,24 @@ struct QuerySlot {                // everything one in-flight online query owns
     uint32_t acc_launches = 0, acc_queries = 0;
 };
 
+struct PlanSig {         // everything a bulk plan is built from: a cached plan is reused only when ALL of it is unchanged
+    uint64_t db_generation = 0;
+    size_t n_db = 0;     // stored frames (appends only add slots, a clear / truncate / load bumps db_generation)
+    int n_q = 0, gap = 0, q_stride = 0, item_slots = 0, pack_mode = 0;
+    bool self = false;
+    size_t scratch_words = 0;
+    std::vector<int32_t> q_ids, q_counts;      // external query set only
+    std::vector<uint32_t> q_frame_of;
+    bool operator==(const PlanSig& o) const {
+        return db_generation == o.db_generation && n_db == o.n_db && n_q == o.n_q && gap == o.gap && q_stride == o.q_stride &&
+               item_slots == o.item_slots && pack_mode == o.pack_mode && self == o.self && scratch_words == o.scratch_words &&
+               q_ids == o.q_ids && q_counts == o.q_counts && q_frame_of == o.q_frame_of;
+    }
+};
+
 struct Plan {            // cached work list of one bulk call shape
-    uint64_t key = 0;    // hash of what it was built from
+    uint64_t key = 0;    // 0 = invalid (set by everything that changes the database or the parameters); else sig is compared
+    PlanSig sig;
     std::vector<lcm::WorkItem> items;
     std::vector<size_t> offsets;    // per query frame, start of its run of pairs (n_q + 1)
     lcm::WorkItem* d_items = nullptr;
@@ -108,9 +124,11 @@ struct Plan {            // cached work list of one bulk call shape
     size_t n_pairs = 0;
     uint64_t distances = 0, algo_bytes = 0;
     int max_q_rows = 0;
-    // PACKED form (lcm_kernels.h, ScoreArgs::pk_*): `items` then holds (column, slot run) items chunk by chunk and
-    // d_pk_tab = [pair offsets (n_q + 1) | query row counts (n_q) | per chunk: vstart (n_pos + 1), qframe, elig, pairs]
-    struct PackedChunk { uint32_t item0, n_items, tab0, n_pos, pair_base, n_pairs; };
+    // PACKED form (lcm_kernels.h, ScoreArgs::pk_*): a chunk = one GROUP of query frames (laid end to end in a virtual row
+    // space) x one RANGE of stored slots; `items` holds (column, slot run) items chunk by chunk and
+    // d_pk_tab = [pair offsets (n_q + 1) | query row counts (n_q) | per group: vstart (n_pos + 1), qframe, elig, cidx |
+    //             per chunk: local pair offsets (n_pos + 1)]
+    struct PackedChunk { uint32_t item0, n_items, tab0, ptab0, n_pos, slot0, n_pairs; };
     bool packed = false;
     std::vector<PackedChunk> pk_chunks;
     uint32_t* d_pk_tab = nullptr;
@@ -133,15 +151,26 @@ struct lcm_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t copy_stream = nullptr;
+    // packed bulk search of more than one chunk: the chunks alternate between `stream` and `stream2` (and between the two
+    // halves of the per-row scratch), so that the draining tail of one chunk's launch is filled by the next chunk's workgroups
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t db_ready = nullptr;     // last append landed (recorded on copy_stream)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_aux_start = nullptr, ev_aux_stop = nullptr;   // the follow-up kernel of a call (k_loop_test, ...)
     bool aux_pending = false;
+    // packed bulk search: one (start, stop) event pair around EVERY chunk's fold kernel; aux_kernel_ms is their sum
+    std::vector<hipEvent_t> fold_ev;
+    size_t fold_ev_used = 0;
     int variant = 0;
     int tune_item_slots = 0;           // 0 = automatic (pick_chunk)
     int tune_online_split = -1;        // -1 = automatic (enqueue_query)
     int tune_online_streams = 1;       // 1 = every query slot runs on its own stream, 0 = all on the handle's stream
-    size_t pk_scratch_words = (size_t)1 << 31;   // packed route: words of per-row scratch per chunk (halved after an OOM)
+    // packed route: 4-byte words of per-row scratch per chunk.  _cfg is what LCM_TUNE_PACKED_SCRATCH_MB asked for (default
+    // 1 GiB); the effective size is halved when the allocation fails and goes back to _cfg at the next plan rebuild.
+    size_t pk_scratch_cfg_words = (size_t)1 << 28;
+    size_t pk_scratch_words = (size_t)1 << 28;
+    bool pk_oom_retry = false;
     int tune_packed = -1;              // -1 = automatic (bulk plan: when it saves lane slots), 0 = never, 1 = always
 
     // database arena
@@ -237,6 +266,10 @@ int mfma_bulk(lcm_handle* h, bool self, const uint8_t* q_rows, const int32_t* d_
 int all_vs_all(lcm_handle* h, const void* d_query_rows, const int32_t* d_query_counts, const int32_t* q_ids,
                int n_q_frames, int q_stride_rows, void* d_scores, size_t scores_cap, size_t* n_pairs,
                size_t* pair_offsets, uint32_t* d_idx_sums, const uint32_t* q_frame_of, const int32_t* h_query_counts);
+// Loop test + ordered compaction over a score array on h's device (lcm_all_vs_all_loops; a group's shard over its own records)
+int loop_test_device(lcm_handle* h, const void* d_scores, size_t n_pairs, const uint32_t* offsets, int n_q,
+                     const int32_t* q_ids, const int32_t* q_kp, int n_db, const int32_t* db_ids, const int32_t* db_kp,
+                     size_t cap, size_t* n_found);
 }  // namespace lcm
 
 namespace {

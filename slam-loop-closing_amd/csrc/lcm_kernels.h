@@ -54,12 +54,16 @@ struct ScoreArgs {
     // of bat_nq[b] rows stored at chunk index b * imp_chunks of q_rows, scored against stored slots [0, bat_elig[b]);
     // its workgroups are [bat_wg[b], bat_wg[b + 1]) and its records start at pair index bat_pair[b].  imp_chunks,
     // imp_chunk_rows and imp_spi are shared by the whole batch.
-    // PACKED bulk mode (launch_score_packed): the query rows of consecutive query frames form one virtual row space cut
-    // into 2048-row workgroups, so a 2000-row frame no longer leaves 48 of 2048 lane slots idle.  Work item: q_frame =
-    // workgroup index w in that space (virtual rows [2048 w, 2048 w + 2048)), slots as usual.  Per query frame c of the
-    // chunk (pk_n of them): pk_vstart[c] = its first virtual row (pk_vstart[pk_n] = total), pk_qframe[c] = its index in
-    // q_rows, pk_elig[c] = eligible stored slots, pk_pairs[c] = its first pair in pk_dist.  Output: the best distance
-    // (ARGMIN: packed key) of every (pair, query row) -> pk_dist[pair * pk_stride + row]; launch_finalize_bulk folds them.
+    // PACKED bulk mode (launch_score_packed): the query rows of a GROUP of query frames form one virtual row space cut
+    // into 2048-row workgroups, so a 2000-row frame no longer leaves 48 of 2048 lane slots idle.  A launch (chunk) covers
+    // one group against one RANGE of stored slots [pk_slot0, ...): the scratch holds only that range's pairs, so its
+    // size does not limit how many frames share the row space.  Work item: q_frame = workgroup index w in that space
+    // (virtual rows [2048 w, 2048 w + 2048)), slots as usual (inside the chunk's range).  Per query frame k of the group
+    // (pk_n of them): pk_vstart[k] = its first virtual row (pk_vstart[pk_n] = total), pk_qframe[k] = its index in
+    // q_rows, pk_elig[k] = its eligible stored slots (global), pk_pairs[k] = its first pair in this chunk's pk_dist
+    // (pk_pairs[pk_n] = the chunk's pair count).  Output: the best distance (as a uint16; ARGMIN: the packed key, a
+    // uint32) of every (pair, query row) -> word (pk_pairs[k] + slot - pk_slot0) * pk_stride + row of pk_dist;
+    // launch_finalize_bulk folds them.
     // Query frames may exceed 2048 rows here (they span columns); every other route stops at MAX_FUSED_QUERY_ROWS.
     const uint32_t* pk_vstart;
     const uint32_t* pk_qframe;
@@ -69,6 +73,7 @@ struct ScoreArgs {
     uint32_t        pk_n;
     uint32_t        pk_col_rows;  // rows per column (workgroup): 2048 (8 rows per lane) or 1536 (6 rows per lane)
     uint32_t        pk_stride;    // words of pk_dist per pair: 2048, or the largest query frame rounded up when above that
+    uint32_t        pk_slot0;     // first stored slot of the chunk's range
     uint32_t        imp_nbatch;
     uint32_t        bat_wg[MAX_QUERY_BATCH + 1];
     uint32_t        bat_pair[MAX_QUERY_BATCH + 1];
@@ -139,7 +144,11 @@ struct LoopTestArgs {
     int32_t         min_matches;
     double          sim_threshold;
 };
-hipError_t launch_loop_test(const LoopTestArgs& a, hipStream_t st);
+// Two steps, so that the host can size the candidate buffer from the count (and refuse a too-small `cap` before any
+// worst-case allocation): launch_loop_count leaves the number of candidates in *counter (and the per-block prefix in
+// block_counts); launch_loop_emit then writes candidate k < cap to out[k].
+hipError_t launch_loop_count(const LoopTestArgs& a, hipStream_t st);
+hipError_t launch_loop_emit(const LoopTestArgs& a, hipStream_t st);
 
 // Cross-check (lcm_params.cross_check, BFMatcher crossCheck = true): per pair, forward keys (every query row's first
 // nearest train row) and backward keys (every train row's first nearest query row) -> the pair's score record.
@@ -207,10 +216,17 @@ hipError_t launch_expand_fp4(const uint32_t* rows, const int32_t* counts, uint32
                              uint32_t tiles_per_frame, uint8_t* img, hipStream_t st);
 hipError_t launch_score_mfma_fp4(const MfmaArgs& a, uint32_t n_items, hipStream_t st);
 
-// Pair p (global index, pair_base <= p < pair_base + n_pairs) belongs to query c = last c with offsets[c] <= p and is
-// stored slot p - offsets[c]; folds dist[(p - pair_base) * stride + r], r < nq[c], into the pair's score record.
+// Fold of per-row words into score records, one wave per pair.  Which pair a scratch slot l (0 <= l < n_pairs) is:
+//   * pk_pairs == NULL (matrix-core variants): global pair p = pair_base + l belongs to query c = last c with
+//     offsets[c] <= p and is stored slot p - offsets[c];
+//   * pk_pairs != NULL (packed route, a chunk = group of query frames x range of stored slots): l belongs to the group's
+//     frame k = last k with pk_pairs[k] <= l, is stored slot slot0 + l - pk_pairs[k], query c = pk_cidx[k], and its
+//     record is scores[offsets[c] + slot].
+// Folds dist[l * stride + r], r < nq[c].
 struct FinalizeBulkArgs {
-    uint32_t        stride;        // words of dist per pair (0 = MAX_FUSED_QUERY_ROWS); a multiple of 4
+    uint32_t        stride;        // words of dist per pair (0 = MAX_FUSED_QUERY_ROWS); a multiple of 8
+    uint32_t        word_bytes;    // 4 (0 means 4): dist holds uint32 words; 2: uint16 distances, 0xFFFF = none (packed
+                                   // route, distance-only mode: halves the scratch traffic); keys are always 4 bytes
     int32_t         key_shift;     // 0: dist holds distances; KEY_SHIFT: packed keys dist << 22 | train row
     uint32_t*       idx_sums;      // optional (keys): per pair, sum of the good matches' train rows mod 2^32
     const uint32_t* dist;
@@ -220,6 +236,9 @@ struct FinalizeBulkArgs {
     void*           scores;        // records at scores[p]
     uint32_t        n_q, pair_base;
     int32_t         ratio, dist_floor;
+    const uint32_t* pk_pairs;      // packed route: pk_n + 1 local pair offsets of the group's frames in this chunk
+    const uint32_t* pk_cidx;       // packed route: query index c of the group's frame k
+    uint32_t        pk_n, slot0;
 };
 hipError_t launch_finalize_bulk(const FinalizeBulkArgs& a, uint32_t n_pairs, hipStream_t st);
 
@@ -234,6 +253,7 @@ struct MergeArgs {
     const uint32_t* offsets;       // n_q + 1 per-query offsets of the merged array
     uint32_t        shard_base[9]; // W + 1 entries (W <= 8)
     uint32_t        world, n_q, n_total;
+    uint32_t        elem_words;    // 2: lcm_score records (0 means 2); 1: the argmin search's per-pair index checksums
 };
 hipError_t launch_merge_shards(const MergeArgs& a, hipStream_t st);
 

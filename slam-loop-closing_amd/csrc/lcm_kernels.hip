@@ -13,9 +13,11 @@
 //   * the train rows are wave-uniform: they are read with s_load_dwordx16 from the constant address space into
 //     SGPRs and used directly as the scalar operand of v_xor_b32 — no LDS traffic, no VGPRs, no cross-lane work
 //     in the inner loop;
-//   * per-query running minimum folded with v_min3_u32: the bare distance for the loop search (ARGMIN = false: a
-//     LoopCandidate carries no train index), or a packed key (dist << 22 | train_idx) when match lists are wanted
-//     (ARGMIN = true) — the lowest train index then wins ties for free (strict-'<' scan of OpenCV's batchDistance);
+//   * per-query running minimum DISTANCE folded with v_min3_u32; the throughput modes carry no train index in the
+//     inner loop.  The first train row attaining the minimum (cv::BFMatcher's trainIdx: strict-'<' ascending scan of OpenCV's
+//     batchDistance) comes from 8-row group keys kept in lane-private LDS words + a re-scan of the winning group
+//     (ARGMIN_MODE 1, the bulk search), or from a packed key dist << 22 | train_idx per distance (ARGMIN_MODE 2, the
+//     pair mode, where a launch is too small to hide the re-scan's dependent loads);
 //   * per pair, the min-of-mins and the good-match count are LDS-atomic reductions (ds_min_u32 / ds_add_u32) over
 //     the workgroup's lanes.
 //
@@ -354,7 +356,12 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : (ARGMIN_MODE ==
                 const uint32_t c = lane_meta[j * THREADS + tid];
                 if (c == 0xFFFFFFFFu) continue;
                 const uint32_t r = col0 + (uint32_t)(j * THREADS + tid) - a.pk_vstart[c];
-                if (slot < a.pk_elig[c]) a.pk_dist[((size_t)a.pk_pairs[c] + slot) * a.pk_stride + r] = lane_key[j * THREADS + tid];
+                if (slot < a.pk_elig[c]) {
+                    const size_t w = ((size_t)a.pk_pairs[c] + (slot - a.pk_slot0)) * a.pk_stride + r;
+                    // distance-only: a best distance is <= 256 (0xFFFF: the stored frame is empty) -> 2-byte scratch words
+                    if (GROUPED) a.pk_dist[w] = lane_key[j * THREADS + tid];
+                    else reinterpret_cast<uint16_t*>(a.pk_dist)[w] = (uint16_t)lane_key[j * THREADS + tid];
+                }
             }
             continue;
         }
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : (ARGMIN_MODE ==
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Variant 1: the mapping BASELINE.json's north_star sketches — lanes own TRAIN rows (coalesced 16-byte loads, 8 rows
+// Variants 2 / 3 (k_score_trainlane): the mapping BASELINE.json's north_star sketches — lanes own TRAIN rows (coalesced 16-byte loads, 8 rows
 // per lane = a whole 2048-row stored frame in a workgroup's registers), QUERY rows staged in LDS in 256-row tiles and
 // broadcast to all lanes with ds_read_b128, per-query min(/argmin) by a wavefront __shfl_xor reduction, waves combined
 // with ds_min_u32.  Kept selectable (lcm_set_kernel_variant(2) / 3) so that the choice of variant 0 rests on a
@@ -758,12 +765,17 @@ __global__ __launch_bounds__(256) void k_loop_emit(LoopTestArgs a) {
     if (k < a.cap) reinterpret_cast<CandidateRec*>(a.out)[k] = r;
 }
 
-hipError_t launch_loop_test(const LoopTestArgs& a, hipStream_t st) {
+hipError_t launch_loop_count(const LoopTestArgs& a, hipStream_t st) {
     if (a.n_pairs == 0) return hipSuccess;
     const uint32_t n_blocks = (a.n_pairs + 255) / 256;
     hipLaunchKernelGGL(k_loop_count, dim3(n_blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, a.block_counts, n_blocks, a.counter);
-    hipLaunchKernelGGL(k_loop_emit, dim3(n_blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_loop_emit(const LoopTestArgs& a, hipStream_t st) {
+    if (a.n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_loop_emit, dim3((a.n_pairs + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -851,7 +863,9 @@ __global__ __launch_bounds__(256) void k_merge_shards(MergeArgs a) {
         if (off_r[mid] <= li) lo = mid; else hi = mid;
     }
     const uint32_t k = li - off_r[lo];
-    reinterpret_cast<uint2*>(a.merged)[a.offsets[lo] + r + k * a.world] = reinterpret_cast<const uint2*>(a.gathered)[i];
+    const uint32_t dst = a.offsets[lo] + r + k * a.world;
+    if (a.elem_words == 1) reinterpret_cast<uint32_t*>(a.merged)[dst] = reinterpret_cast<const uint32_t*>(a.gathered)[i];
+    else reinterpret_cast<uint2*>(a.merged)[dst] = reinterpret_cast<const uint2*>(a.gathered)[i];
 }
 
 hipError_t launch_merge_shards(const MergeArgs& a, hipStream_t st) {
@@ -860,8 +874,9 @@ hipError_t launch_merge_shards(const MergeArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// variant 0: row-per-lane, bulk scoring tracks distances only (default)
-// variant 1: row-per-lane, bulk scoring tracks full (dist, idx) keys too (the kernel the pair mode always uses)
+// variant 0: row-per-lane, best distance per query row (default for lcm_all_vs_all and the online queries)
+// variant 1: row-per-lane, + the first train row attaining it by 8-row group keys and a re-scan (lcm_all_vs_all_argmin)
+// write_keys: a packed key per distance and per-row keys written out (pair mode / match lists), whatever the variant
 // variant 2 / 3: north_star's train-row-per-lane mapping, distances only / keys (stored frames of <= 2048 rows)
 // All selectable so they can be measured on the same workload (bench.py --variant N).
 hipError_t launch_score(const ScoreArgs& a, uint32_t n_items, int max_query_rows, bool write_keys, int variant,

@@ -293,6 +293,31 @@ hipError_t launch_score_mfma_fp4(const MfmaArgs& a, uint32_t n_items, hipStream_
     return hipGetLastError();
 }
 
+// Which pair scratch slot `local` of a fold launch holds (FinalizeBulkArgs): global pair index p (where its record goes),
+// stored slot, and the query frame's row count.
+__device__ __forceinline__ void fold_locate(const FinalizeBulkArgs& a, uint32_t local, uint32_t& p, uint32_t& slot, int& nq) {
+    if (a.pk_pairs) {                                           // packed route: group of query frames x range of stored slots
+        uint32_t lo = 0, hi = a.pk_n;                           // last k with pk_pairs[k] <= local
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.pk_pairs[mid] <= local) lo = mid; else hi = mid;
+        }
+        const uint32_t c = a.pk_cidx[lo];
+        slot = a.slot0 + (local - a.pk_pairs[lo]);
+        p = a.offsets[c] + slot;
+        nq = a.nq[c];
+        return;
+    }
+    p = a.pair_base + local;
+    uint32_t lo = 0, hi = a.n_q;                                // last c with offsets[c] <= p
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.offsets[mid] <= p) lo = mid; else hi = mid;
+    }
+    nq = a.nq[lo];
+    slot = p - a.offsets[lo];
+}
+
 // ---- per-pair fold of the best distances ---------------------------------------------------------------------------
 // One WAVE per pair: a pair's <= 2048 per-row words are read once, 8 coalesced 16-byte loads per lane (1 KiB per wave
 // load), and stay in 32 registers for both passes (min-of-mins, then the ratio-filter count); the two wave reductions
@@ -301,14 +326,9 @@ __global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a, uint3
     const int lane = threadIdx.x & 63;
     const uint32_t local = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (local >= n_pairs) return;                               // whole wave: no barrier follows
-    const uint32_t p = a.pair_base + local;
-    uint32_t lo = 0, hi = a.n_q;                                // last c with offsets[c] <= p
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a.offsets[mid] <= p) lo = mid; else hi = mid;
-    }
-    const int nq = a.nq[lo];
-    const uint32_t slot = p - a.offsets[lo];
+    uint32_t p, slot;
+    int nq;
+    fold_locate(a, local, p, slot, nq);
     const uint32_t stride = a.stride ? a.stride : (uint32_t)MAX_FUSED_QUERY_ROWS;
     const uint4* d = reinterpret_cast<const uint4*>(a.dist + (size_t)local * stride);
     const int sh = a.key_shift;
@@ -364,8 +384,65 @@ __global__ __launch_bounds__(256) void k_finalize_bulk(FinalizeBulkArgs a, uint3
     }
 }
 
+// The same fold over 2-byte words (the packed route's distance-only scratch: a best distance is <= 256, 0xFFFF = the
+// stored frame is empty): 4 coalesced 16-byte loads per lane instead of 8, half the scratch traffic.
+__global__ __launch_bounds__(256) void k_finalize_bulk_u16(FinalizeBulkArgs a, uint32_t n_pairs) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t local = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (local >= n_pairs) return;                               // whole wave: no barrier follows
+    uint32_t p, slot;
+    int nq;
+    fold_locate(a, local, p, slot, nq);
+    const uint32_t stride = a.stride ? a.stride : (uint32_t)MAX_FUSED_QUERY_ROWS;
+    const uint16_t* w = reinterpret_cast<const uint16_t*>(a.dist) + (size_t)local * stride;
+    uint32_t dmin = 0xFFFFu, cnt = 0;
+    if (nq <= MAX_FUSED_QUERY_ROWS) {
+        uint32_t v[32];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r0 = (i * 64 + lane) * 8;                 // rows r0 .. r0 + 7; rows >= nq hold stale words: masked
+            uint4 x = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (r0 < nq) x = reinterpret_cast<const uint4*>(w)[i * 64 + lane];
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[8 * i + 2 * k] = r0 + 2 * k < nq ? (xs[k] & 0xFFFFu) : 0xFFFFu;
+                v[8 * i + 2 * k + 1] = r0 + 2 * k + 1 < nq ? (xs[k] >> 16) : 0xFFFFu;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) dmin = min(dmin, v[k]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+        const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) cnt += (v[k] != 0xFFFFu && v[k] <= thr) ? 1u : 0u;
+    } else {
+        for (int r = lane; r < nq; r += 64) dmin = min(dmin, (uint32_t)w[r]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+        const uint32_t thr = max((uint32_t)a.ratio * dmin, (uint32_t)a.dist_floor);
+        for (int r = lane; r < nq; r += 64) { const uint32_t x = w[r]; cnt += (x != 0xFFFFu && x <= thr) ? 1u : 0u; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+    if (lane == 0) {
+        const int nt = a.db_counts[slot];
+        const bool empty = (nq <= 0) || (nt <= 0) || dmin == 0xFFFFu;
+        uint2 rec;
+        rec.x = empty ? 0u : cnt;
+        rec.y = (empty ? 0xFFFFu : (dmin & 0xFFFFu)) | ((uint32_t)(nt & 0xFFFF) << 16);
+        reinterpret_cast<uint2*>(a.scores)[p] = rec;
+    }
+}
+
 hipError_t launch_finalize_bulk(const FinalizeBulkArgs& a, uint32_t n_pairs, hipStream_t st) {
     if (n_pairs == 0) return hipSuccess;
+    if (a.word_bytes == 2) {
+        if (a.key_shift != 0 || a.idx_sums) return hipErrorInvalidValue;      // packed keys are 4-byte words
+        hipLaunchKernelGGL(k_finalize_bulk_u16, dim3((n_pairs + 3) / 4), dim3(256), 0, st, a, n_pairs);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_finalize_bulk, dim3((n_pairs + 3) / 4), dim3(256), 0, st, a, n_pairs);
     return hipGetLastError();
 }

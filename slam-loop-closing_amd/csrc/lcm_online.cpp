@@ -8,6 +8,19 @@
 static inline bool is_split(int qpt) { return qpt == 1 || qpt == 2 || qpt == 4 || qpt == 16 || qpt == 32; }
 static inline int split_chunk_rows(int qpt) { return qpt == 16 ? 512 : qpt == 32 ? 1024 : 256 * qpt; }
 
+// The ONE place that decides whether an online launch is cut into row chunks (split mode), for single queries and
+// micro-batches, at submit time (staging pitch) and at enqueue time alike: 0 = one workgroup per (query, run of stored
+// frames), else the split code.  Only kernel variant 0 has a split form (the A/B variants 1-3 run unsplit, so that their
+// online numbers are their own); frames of <= 512 rows fill too few lanes to be worth cutting.
+// Measured (bench.py --mode stream): finer pieces balance 256 CUs better whenever a launch holds only a few thousand
+// pairs — single query, 1000 frames: 1.71e12 unsplit -> 2.18e12; micro-batches of 8: split below 65536 pairs.
+static int pick_online_split(const lcm_handle* h, int max_nq, size_t pairs, bool batch) {
+    if (h->variant != 0 || max_nq <= 512) return 0;
+    if (h->tune_online_split >= 0) return h->tune_online_split;     // lcm_set_tuning(LCM_TUNE_ONLINE_SPLIT)
+    if (batch) return pairs < 1536 ? 1 : pairs < 6144 ? 2 : pairs < lcm::ONLINE_SPLIT_MAX_PAIRS ? 4 : 0;
+    return pairs < 256 ? 1 : pairs < 3072 ? 2 : pairs < 6144 ? 4 : 0;
+}
+
 extern "C" {
 
 // scores of (query frame at q_rows[q_frame]) against stored slots [0, n_elig)
@@ -43,16 +56,7 @@ static int enqueue_query(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int n
         // (the query is padded to 2048 rows in its own image; d_q may be a stored frame's rows or the staged query)
         return mfma_online(h, q, d_q, std::max(nq, 1), 1, &nq, &n_elig);
     }
-    const int split_env = h->tune_online_split;              // lcm_set_tuning(LCM_TUNE_ONLINE_SPLIT); -1 = automatic
-    int qpt = 0;
-    if (h->variant == 0 && nq > 512) {
-        if (split_env >= 0) qpt = split_env;                 // 0 = never split, 1/2/4 = force that many rows per lane
-        // measured (bench.py --mode stream, LCM_SPLIT sweep): finer pieces balance 256 CUs better whenever a launch
-        // holds only a few thousand pairs — 1000 frames: 1.71e12 unsplit -> 2.18e12; 2500 frames: 2.32e12 -> 2.57e12
-        else if (n_elig < 256) qpt = 1;
-        else if (n_elig < 3072) qpt = 2;
-        else if (n_elig < 6144) qpt = 4;
-    }
+    const int qpt = pick_online_split(h, nq, (size_t)n_elig, false);
     rc = ensure_dev(q.d_scores, q.d_scores_n, (size_t)n_elig); if (rc) return rc;
     rc = ensure_pinned(q.h_scores, q.h_scores_n, (size_t)n_elig); if (rc) return rc;
     lcm::ScoreArgs a{};
@@ -127,13 +131,7 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
         return LCM_OK;
     }
     if (h->variant >= 4) return mfma_online(h, q, d_q, rows_per_query, B, nq, elig);
-    int qpt = 0;
-    if (max_nq > 512) {
-        if (h->tune_online_split >= 0) qpt = h->tune_online_split;
-        else if (total < 1536) qpt = 1;          // same rule as a single query, on the batch's total pair count
-        else if (total < 6144) qpt = 2;
-        else if (total < lcm::ONLINE_SPLIT_MAX_PAIRS) qpt = 4;
-    }
+    const int qpt = pick_online_split(h, max_nq, total, true);
     rc = ensure_dev(q.d_scores, q.d_scores_n, total); if (rc) return rc;
     rc = ensure_pinned(q.h_scores, q.h_scores_n, total); if (rc) return rc;
     lcm::ScoreArgs a{};
@@ -182,6 +180,7 @@ static int enqueue_batch(lcm_handle* h, QuerySlot& q, const uint32_t* d_q, int r
         h->info.launches = 2; h->info.route = LCM_ROUTE_SPLIT;
     } else {
         a.scores = q.d_scores; a.keys = nullptr; a.keys_stride = 0;
+        // (the train-row-per-lane A/B kernels, variants 2 / 3, have no micro-batch form: a batch under them runs variant 0)
         hipError_t e = lcm::launch_score(a, wg, max_nq, false, h->variant >= 2 ? 0 : h->variant, S);
         if (e != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         h->info.launches = 1; h->info.route = LCM_ROUTE_PLAIN;
@@ -374,13 +373,7 @@ static int query_submit_batch_impl(lcm_handle* h, const uint8_t* const* queries,
     // staging pitch: every query gets the same number of rows, a whole number of the chunks enqueue_batch will cut
     int pitch = std::max(max_nq, 1);
     {
-        int qpt = 0;
-        if (max_nq > 512) {
-            if (h->tune_online_split >= 0) qpt = h->tune_online_split;
-            else if (total < 1536) qpt = 1;
-            else if (total < 6144) qpt = 2;
-            else if (total < lcm::ONLINE_SPLIT_MAX_PAIRS) qpt = 4;
-        }
+        const int qpt = pick_online_split(h, max_nq, total, true);       // the same call enqueue_batch makes
         if (is_split(qpt)) pitch = round_up(max_nq, split_chunk_rows(qpt));
     }
     if (h->params.cross_check) pitch = padded_rows(std::max(max_nq, 1)) + 2 * ROW_PAD;   // room for every query's padding rows

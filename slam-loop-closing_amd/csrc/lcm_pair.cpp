@@ -129,18 +129,17 @@ static void cross_combine(int mode, const uint32_t* fkeys, int nq, const uint32_
 // One pair with rows from the host and / or the device: host rows travel inside the staging block (a matrix in the TRAIN
 // role with its padding rows — copies of the last row — written straight into pinned memory: no extra copies).
 // With cross_check the pair runs twice, roles swapped the second time, and the two key arrays are combined.
-static int pair_keys(lcm_handle* h, RowSrc q, RowSrc t, std::vector<uint32_t>& keys_out) {
+// `cross` = the cross-check mode to apply (the handle's, for the outer call; 0 for the two one-directional passes the
+// cross-check itself is made of).  It is an ARGUMENT: the handle's parameters are never touched, so no failure in the
+// nested passes — an exception included — can leave the handle with its cross-check switched off.
+static int pair_keys(lcm_handle* h, RowSrc q, RowSrc t, std::vector<uint32_t>& keys_out, int cross) {
     int rc = set_device(h); if (rc) return rc;
-    if (h->params.cross_check) {
+    if (cross) {
         if (q.n > LCM_MAX_TRAIN_ROWS) return fail(LCM_ERR_CAPACITY, "cross_check: at most %d query rows", LCM_MAX_TRAIN_ROWS);
-        lcm_params saved = h->params;
-        h->params.cross_check = 0;
         std::vector<uint32_t> fk, bk;
-        rc = pair_keys(h, q, t, fk);
-        if (!rc) rc = pair_keys(h, t, q, bk);
-        h->params = saved;
-        if (rc) return rc;
-        cross_combine(saved.cross_check, fk.data(), q.n, bk.data(), t.n, keys_out);
+        rc = pair_keys(h, q, t, fk, 0); if (rc) return rc;
+        rc = pair_keys(h, t, q, bk, 0); if (rc) return rc;
+        cross_combine(cross, fk.data(), q.n, bk.data(), t.n, keys_out);
         return LCM_OK;
     }
     const size_t q_bytes = q.dev ? 0 : (size_t)q.n * LCM_DESC_BYTES;
@@ -213,7 +212,7 @@ static int match_pair_impl(lcm_handle* h, const uint8_t* query, int nq, const ui
     if (nq == 0 || nt == 0) return LCM_OK;            // BFMatcher: no train rows => no matches
     if (!query || !train || !train_idx || !dist) return fail(LCM_ERR_INVALID_ARG, "NULL buffer");
     std::vector<uint32_t> keys;
-    int rc = pair_keys(h, RowSrc{query, nullptr, nq}, RowSrc{train, nullptr, nt}, keys); if (rc) return rc;
+    int rc = pair_keys(h, RowSrc{query, nullptr, nq}, RowSrc{train, nullptr, nt}, keys, h->params.cross_check); if (rc) return rc;
     int n = 0;
     for (int i = 0; i < nq; ++i) {
         if (keys[i] == 0xFFFFFFFFu) { train_idx[i] = -1; dist[i] = 0xFFFF; continue; }   // cross_check: no match for row i
@@ -233,7 +232,7 @@ static int match_features_impl(lcm_handle* h, const uint8_t* query, int nq, cons
     if (nq == 0 || nt == 0) return LCM_OK;
     if (!query || !train || !out) return fail(LCM_ERR_INVALID_ARG, "NULL buffer");
     std::vector<uint32_t> keys;
-    int rc = pair_keys(h, RowSrc{query, nullptr, nq}, RowSrc{train, nullptr, nt}, keys); if (rc) return rc;
+    int rc = pair_keys(h, RowSrc{query, nullptr, nq}, RowSrc{train, nullptr, nt}, keys, h->params.cross_check); if (rc) return rc;
     return filter_keys(h, keys, nq, out, n_out, min_dist);
 }
 
@@ -248,7 +247,7 @@ static int match_stored_impl(lcm_handle* h, int query_frame_id, int train_frame_
     if (q.n == 0 || t.n == 0) return LCM_OK;
     if (!out || cap < q.n) return fail(LCM_ERR_CAPACITY, "need room for %d matches", q.n);
     std::vector<uint32_t> keys;
-    rc = pair_keys(h, q, t, keys); if (rc) return rc;
+    rc = pair_keys(h, q, t, keys, h->params.cross_check); if (rc) return rc;
     return filter_keys(h, keys, q.n, out, n_out, min_dist);
 }
 

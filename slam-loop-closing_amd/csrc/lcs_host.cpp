@@ -42,6 +42,16 @@ LoopClosingSystem::LoopClosingSystem(double loop_threshold, int min_loop_gap, co
     if (lcm_group_handle(group_, 0, &matcher_) != LCM_OK) { lcm_group_destroy(group_); group_ = nullptr; raise("LoopClosingSystem: lcm_group_handle"); }
 }
 
+LoopClosingSystem::LoopClosingSystem(double loop_threshold, int min_loop_gap, Loopback rehearsal)
+    : loop_threshold_(loop_threshold), min_loop_gap_(min_loop_gap), shard_rank_(0), shard_world_(1) {
+    lcm_params p;
+    lcm_params_default(&p);
+    p.sim_threshold = loop_threshold;
+    p.min_gap = min_loop_gap;
+    if (lcm_group_create_loopback(&p, rehearsal.n_shards, rehearsal.device_id, &group_) != LCM_OK) raise("LoopClosingSystem: lcm_group_create_loopback");
+    if (lcm_group_handle(group_, 0, &matcher_) != LCM_OK) { lcm_group_destroy(group_); group_ = nullptr; raise("LoopClosingSystem: lcm_group_handle"); }
+}
+
 LoopClosingSystem::~LoopClosingSystem() {
     if (group_) lcm_group_destroy(group_);      // owns every shard's matcher, matcher_ included
     else lcm_destroy(matcher_);
@@ -57,78 +67,10 @@ const Frame* LoopClosingSystem::findFrame(int frame_id) const {
     return (it != frames_.end() && it->id == frame_id) ? &*it : nullptr;
 }
 
-void LoopClosingSystem::processFrame(const uint8_t* descriptors, int rows, int num_keypoints, int frame_id) {
-    if (rows < 0 || (rows > 0 && !descriptors)) throw std::invalid_argument("processFrame: bad descriptors");
-    if (!frames_.empty() && frame_id <= frames_.back().id) throw std::invalid_argument("processFrame: frame ids must increase");
-    Frame f;
-    f.id = frame_id;
-    f.num_keypoints = num_keypoints < 0 ? rows : num_keypoints;
-    f.descriptors.assign(descriptors, descriptors + (size_t)rows * 32);
-    frames_.push_back(std::move(f));
-    const size_t n_loops_before = loop_closures_.size();
-    try {
-        // consecutive-frame matching (README.md:96-97): previous frame = query, current = train, as the tree's own
-        // incremental loop orders them (src/main.cpp:1154 matchFeatures(lastKF, cur)); pose / triangulation are out of scope
-        // One device: the loop-closure query is SUBMITTED first (asynchronous, on its query slot's own stream), the pair
-        // match then runs on the handle's stream beside it, and the records are collected afterwards — the two steps
-        // of README.md:96-100 overlap on the device instead of queueing.  A group scores synchronously.
-        const Frame& cur = frames_.back();
-        const size_t cur_pos = frames_.size() - 1;
-        static const uint8_t dummy[32] = {0};
-        int ticket = -1;
-        if (!group_ && lcm_query_submit(matcher_, cur.rows() > 0 ? cur.descriptors.data() : dummy, cur.rows(), keyOf(cur_pos), &ticket) != LCM_OK)
-            raise("processFrame: lcm_query_submit");
-        consecutive_matches_.clear();
-        try {
-            if (frames_.size() >= 2) consecutive_matches_ = matchFeatures(frames_[frames_.size() - 2], frames_.back());
-        } catch (...) {
-            if (ticket >= 0) {                                   // drain the query that is in flight, keep the first error
-                std::vector<lcm_score> sink((size_t)std::max(lcm_db_size(matcher_), 1));
-                int n = 0;
-                const std::string why = lcm_last_error();
-                (void)lcm_query_collect(matcher_, ticket, sink.data(), nullptr, (int)sink.size(), &n);
-                lcm::set_last_error(why.c_str());
-            }
-            throw;
-        }
-        // loop-closure check against the frames stored so far (the current frame is the query, README.md:100,122) ...
-        if (group_) {
-            std::vector<LoopCandidate> found = detectLoops(frame_id);
-            loop_closures_.insert(loop_closures_.end(), found.begin(), found.end());
-        } else {
-            std::vector<lcm_score> sc((size_t)std::max(lcm_db_size(matcher_), 1));
-            int n = 0;
-            if (lcm_query_collect(matcher_, ticket, sc.data(), nullptr, (int)sc.size(), &n) != LCM_OK) raise("processFrame: lcm_query_collect");
-            lcm_params p;
-            if (lcm_get_params(matcher_, &p) != LCM_OK) raise("processFrame: lcm_get_params");
-            for (int k = 0; k < n; ++k) {                        // record k = the k-th stored frame this rank owns
-                const Frame& past = frames_[(size_t)shard_rank_ + (size_t)k * (size_t)shard_world_];
-                double sim = 0.0;
-                if (lcm_loop_test(&p, &sc[(size_t)k], cur.num_keypoints, past.num_keypoints, &sim))
-                    loop_closures_.push_back({cur.id, past.id, (int)sc[(size_t)k].good_count, sim});
-            }
-        }
-        // ... then the frame joins the device database if this rank owns its position
-        const size_t pos = frames_.size() - 1;
-        const Frame& s = frames_.back();
-        if (group_) {
-            if (lcm_group_append(group_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_group_append");
-        } else if (ownsPosition(pos)) {
-            if (lcm_db_append(matcher_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_db_append");
-        }
-    } catch (...) {
-        // strong guarantee: a frame that could not be processed leaves no trace (host list, loop list, device DB agree)
-        frames_.pop_back();
-        loop_closures_.resize(n_loops_before);
-        throw;
-    }
-}
-
-// frames_[first, first + count) are on the host list already, none of them in the device database yet: score them in
-// ONE launch per device against the database as it stands, apply the loop test, then store them.
-void LoopClosingSystem::processBatch(size_t first, size_t count, size_t& stored, std::vector<size_t>& closure_marks) {
-    stored = 0;
-    closure_marks.clear();
+// ---- the three steps every frame goes through, for one device, one shard of a process-per-GPU run, or a group ----------
+// submit: frames_[first, first + count) — on the host list already, none of them in the device database yet — are sent
+// to the device(s) as ONE asynchronous micro-batch (one launch per device) against the database as it stands.
+int LoopClosingSystem::submitBatch(size_t first, size_t count) {
     static const uint8_t dummy[32] = {0};
     std::vector<const uint8_t*> q(count);
     std::vector<int> nq(count), keys(count);
@@ -138,22 +80,26 @@ void LoopClosingSystem::processBatch(size_t first, size_t count, size_t& stored,
         nq[k] = f.rows();
         keys[k] = keyOf(first + k);
     }
+    int ticket = -1;
+    const int rc = group_ ? lcm_group_query_submit_batch(group_, q.data(), nq.data(), keys.data(), (int)count, &ticket)
+                          : lcm_query_submit_batch(matcher_, q.data(), nq.data(), keys.data(), (int)count, &ticket);
+    if (rc != LCM_OK) raise("processFrame: query submit");
+    return ticket;
+}
+
+// collect: wait for that batch, apply the loop test (README.md:123-126) and record the closures, query by query.
+void LoopClosingSystem::collectBatch(int ticket, size_t first, size_t count) {
     const size_t n_db = (size_t)std::max(group_ ? lcm_group_db_size(group_) : lcm_db_size(matcher_), 0);
     std::vector<lcm_score> sc(std::max<size_t>(n_db * count, 1));
     std::vector<size_t> offs(count + 1, 0);
     size_t n = 0;
-    if (group_) {
-        if (lcm_group_query_scores_batch(group_, q.data(), nq.data(), keys.data(), (int)count, sc.data(), sc.size(), &n, offs.data()) != LCM_OK)
-            raise("processFrames: lcm_group_query_scores_batch");
-    } else {
-        int ticket = -1;
-        if (lcm_query_submit_batch(matcher_, q.data(), nq.data(), keys.data(), (int)count, &ticket) != LCM_OK) raise("processFrames: lcm_query_submit_batch");
-        if (lcm_query_collect_batch(matcher_, ticket, sc.data(), sc.size(), &n, offs.data()) != LCM_OK) raise("processFrames: lcm_query_collect_batch");
-    }
+    const int rc = group_ ? lcm_group_query_collect_batch(group_, ticket, sc.data(), sc.size(), &n, offs.data())
+                          : lcm_query_collect_batch(matcher_, ticket, sc.data(), sc.size(), &n, offs.data());
+    if (rc != LCM_OK) raise("processFrame: query collect");
     // Record k of query b is its k-th eligible stored frame.  One device (or a group): that is position k.  One shard of
     // a process-per-GPU run: the k-th frame THIS rank owns, position shard_rank + k * shard_world.
     lcm_params p;
-    if (lcm_get_params(matcher_, &p) != LCM_OK) raise("processFrames: lcm_get_params");
+    if (lcm_get_params(matcher_, &p) != LCM_OK) raise("processFrame: lcm_get_params");
     for (size_t b = 0; b < count; ++b) {
         const Frame& cur = frames_[first + b];
         for (size_t k = offs[b]; k < offs[b + 1]; ++k) {
@@ -163,17 +109,78 @@ void LoopClosingSystem::processBatch(size_t first, size_t count, size_t& stored,
             if (lcm_loop_test(&p, &sc[k], cur.num_keypoints, past.num_keypoints, &sim))
                 loop_closures_.push_back({cur.id, past.id, (int)sc[k].good_count, sim});
         }
-        closure_marks.push_back(loop_closures_.size());        // closures recorded up to and including query b
     }
-    for (size_t k = 0; k < count; ++k) {
-        const size_t pos = first + k;
-        const Frame& s = frames_[pos];
-        if (group_) {
-            if (lcm_group_append(group_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrames: lcm_group_append");
-        } else if (ownsPosition(pos)) {
-            if (lcm_db_append(matcher_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrames: lcm_db_append");
+}
+
+// a ticket whose result is no longer wanted (an error is on its way up): wait for it, keep the first error's message
+void LoopClosingSystem::drainBatch(int ticket, size_t count) noexcept {
+    try {
+        const std::string why = lcm_last_error();
+        const size_t n_db = (size_t)std::max(group_ ? lcm_group_db_size(group_) : lcm_db_size(matcher_), 0);
+        std::vector<lcm_score> sink(std::max<size_t>(n_db * count, 1));
+        size_t n = 0;
+        if (group_) (void)lcm_group_query_collect_batch(group_, ticket, sink.data(), sink.size(), &n, nullptr);
+        else (void)lcm_query_collect_batch(matcher_, ticket, sink.data(), sink.size(), &n, nullptr);
+        lcm::set_last_error(why.c_str());
+    } catch (...) {}
+}
+
+// store: the frame joins the device database (if this rank owns its position)
+void LoopClosingSystem::storeFrame(size_t pos) {
+    const Frame& s = frames_[pos];
+    if (group_) {
+        if (lcm_group_append(group_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_group_append");
+    } else if (ownsPosition(pos)) {
+        if (lcm_db_append(matcher_, keyOf(pos), s.descriptors.data(), s.rows(), s.num_keypoints) != LCM_OK) raise("processFrame: lcm_db_append");
+    }
+}
+
+// the device database back to the first n_frames frames of frames_ (rollback; errors are swallowed: one is on its way up)
+void LoopClosingSystem::truncateDevice(size_t n_frames) noexcept {
+    const std::string why = lcm_last_error();
+    if (group_) (void)lcm_group_truncate(group_, (int)n_frames);
+    else {
+        const size_t r = (size_t)shard_rank_, w = (size_t)shard_world_;
+        (void)lcm_db_truncate(matcher_, (int)(n_frames > r ? (n_frames - r + w - 1) / w : 0));
+    }
+    lcm::set_last_error(why.c_str());
+}
+
+void LoopClosingSystem::processFrame(const uint8_t* descriptors, int rows, int num_keypoints, int frame_id) {
+    if (rows < 0 || (rows > 0 && !descriptors)) throw std::invalid_argument("processFrame: bad descriptors");
+    if (!frames_.empty() && frame_id <= frames_.back().id) throw std::invalid_argument("processFrame: frame ids must increase");
+    Frame f;
+    f.id = frame_id;
+    f.num_keypoints = num_keypoints < 0 ? rows : num_keypoints;
+    f.descriptors.assign(descriptors, descriptors + (size_t)rows * 32);
+    frames_.push_back(std::move(f));
+    const size_t pos = frames_.size() - 1;
+    const size_t n_loops_before = loop_closures_.size();
+    bool stored = false;
+    try {
+        // The loop-closure query (the current frame against the frames stored so far, README.md:100,122) is SUBMITTED first
+        // — asynchronous, on a query slot's own stream, on every device of a group from that device's host thread — the
+        // consecutive-frame pair match (README.md:96-97: previous frame = query, current = train, as the tree's own
+        // incremental loop orders them, src/main.cpp:1154) then runs on the handle's stream beside it, and the records are
+        // collected afterwards: the two steps overlap on the device instead of queueing.
+        const int ticket = submitBatch(pos, 1);
+        consecutive_matches_.clear();
+        try {
+            if (frames_.size() >= 2) consecutive_matches_ = matchFeatures(frames_[frames_.size() - 2], frames_.back());
+        } catch (...) {
+            drainBatch(ticket, 1);
+            throw;
         }
-        stored = k + 1;                                        // frame `pos` is in the device database (or another rank's)
+        collectBatch(ticket, pos, 1);
+        // ... then the frame joins the device database
+        storeFrame(pos);
+        stored = true;
+    } catch (...) {
+        // strong guarantee: a frame that could not be processed leaves no trace (host list, loop list, device DB agree)
+        (void)stored;
+        frames_.pop_back();
+        loop_closures_.resize(n_loops_before);
+        throw;
     }
 }
 
@@ -186,36 +193,65 @@ void LoopClosingSystem::processFrames(const FrameInput* in, int n) {
         last_id = in[i].frame_id;
     }
     const int span = std::max(min_loop_gap_, 1);            // frames of one launch must not be eligible for one another
+    // Two micro-batches in flight: batch k + 1 is submitted (and its frames stored) before batch k is collected, so the
+    // devices never wait for the host between launches.  `done` = frames whose loop check has been collected and recorded.
+    struct InFlight { int ticket = -1; size_t first = 0, count = 0; };
+    InFlight pending;
+    size_t done = frames_.size();
+    const size_t closures_before = loop_closures_.size();
+    (void)closures_before;
     int i = 0;
-    while (i < n) {
-        const size_t first = frames_.size();
-        const size_t closures_before = loop_closures_.size();
-        int cnt = 0;
-        // greedy cut: at most 16 frames, key(last) - key(first) < span
-        while (i + cnt < n && cnt < 16) {
-            const long long k0 = gap_by_position_ ? (long long)first : (long long)in[i].frame_id;
-            const long long kc = gap_by_position_ ? (long long)(first + (size_t)cnt) : (long long)in[i + cnt].frame_id;
-            if (cnt > 0 && kc - k0 >= span) break;
-            ++cnt;
+    try {
+        while (i < n) {
+            const size_t first = frames_.size();
+            int cnt = 0;
+            // greedy cut: at most 16 frames, key(last) - key(first) < span
+            while (i + cnt < n && cnt < 16) {
+                const long long k0 = gap_by_position_ ? (long long)first : (long long)in[i].frame_id;
+                const long long kc = gap_by_position_ ? (long long)(first + (size_t)cnt) : (long long)in[i + cnt].frame_id;
+                if (cnt > 0 && kc - k0 >= span) break;
+                ++cnt;
+            }
+            for (int k = 0; k < cnt; ++k) {
+                Frame f;
+                f.id = in[i + k].frame_id;
+                f.num_keypoints = in[i + k].num_keypoints < 0 ? in[i + k].rows : in[i + k].num_keypoints;
+                f.descriptors.assign(in[i + k].descriptors, in[i + k].descriptors + (size_t)in[i + k].rows * 32);
+                frames_.push_back(std::move(f));
+            }
+            InFlight cur;
+            cur.first = first; cur.count = (size_t)cnt;
+            cur.ticket = submitBatch(first, (size_t)cnt);
+            try {
+                for (int k = 0; k < cnt; ++k) storeFrame(first + (size_t)k);     // copy stream: overlaps the launch just submitted
+            } catch (...) {
+                drainBatch(cur.ticket, cur.count);
+                throw;
+            }
+            if (pending.ticket >= 0) {
+                const InFlight p = pending;
+                pending = cur;                              // if the collect throws, `cur` is what remains to be drained
+                collectBatch(p.ticket, p.first, p.count);
+                done = p.first + p.count;
+            } else {
+                pending = cur;
+            }
+            i += cnt;
         }
-        for (int k = 0; k < cnt; ++k) {
-            Frame f;
-            f.id = in[i + k].frame_id;
-            f.num_keypoints = in[i + k].num_keypoints < 0 ? in[i + k].rows : in[i + k].num_keypoints;
-            f.descriptors.assign(in[i + k].descriptors, in[i + k].descriptors + (size_t)in[i + k].rows * 32);
-            frames_.push_back(std::move(f));
+        if (pending.ticket >= 0) {
+            const InFlight p = pending;
+            pending.ticket = -1;
+            collectBatch(p.ticket, p.first, p.count);
+            done = p.first + p.count;
         }
-        size_t stored = 0;
-        std::vector<size_t> marks;
-        try {
-            processBatch(first, (size_t)cnt, stored, marks);
-        } catch (...) {
-            // host list, loop list and device database must agree: keep the frames that were stored, with their closures
-            frames_.resize(first + stored);
-            loop_closures_.resize(stored == 0 || marks.size() < stored ? closures_before : marks[stored - 1]);
-            throw;
-        }
-        i += cnt;
+    } catch (...) {
+        // Host list, loop list and device database must agree: the frames whose loop check completed stay (with their
+        // closures, which are the only ones recorded); everything after them is taken back, on the device(s) too.
+        if (pending.ticket >= 0) drainBatch(pending.ticket, pending.count);
+        truncateDevice(done);
+        frames_.resize(done);
+        while (!loop_closures_.empty() && !findFrame(loop_closures_.back().current_frame_id)) loop_closures_.pop_back();
+        throw;
     }
     // consecutive-frame matches of the LAST frame (README.md:96-97): what getConsecutiveMatches() would hold after
     // frame-by-frame processing
@@ -318,6 +354,8 @@ void LoopClosingSystem::saveResults(const std::string& output_dir) {
 struct lcs_system {
     loop_closing::LoopClosingSystem sys;
     lcs_system(double thr, int gap, int dev, int r, int w) : sys(thr, gap, dev, r, w) {}
+    lcs_system(double thr, int gap, const std::vector<int>& devs) : sys(thr, gap, devs) {}
+    lcs_system(double thr, int gap, loop_closing::LoopClosingSystem::Loopback lb) : sys(thr, gap, lb) {}
 };
 
 namespace lcm { void set_last_error(const char* msg); }
@@ -344,6 +382,20 @@ int lcs_create(double loop_threshold, int min_loop_gap, int device_id, int shard
         return lcm_create(nullptr, device_id, nullptr, &probe);   // sets the "no device, no CPU fallback" message
     }
     return guarded([&] { *out = new lcs_system(loop_threshold, min_loop_gap, device_id, shard_rank, shard_world); });
+}
+int lcs_create_group(double loop_threshold, int min_loop_gap, int n_devices, const int* device_ids, int loopback_device, lcs_system** out) {
+    if (!out || n_devices < 1) return LCM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (lcm_device_count() <= 0) {
+        lcm_handle* probe = nullptr;
+        return lcm_create(nullptr, 0, nullptr, &probe);
+    }
+    return guarded([&] {
+        if (loopback_device >= 0) { *out = new lcs_system(loop_threshold, min_loop_gap, loop_closing::LoopClosingSystem::Loopback{n_devices, loopback_device}); return; }
+        std::vector<int> devs((size_t)n_devices);
+        for (int i = 0; i < n_devices; ++i) devs[(size_t)i] = device_ids ? device_ids[i] : i;
+        *out = new lcs_system(loop_threshold, min_loop_gap, devs);
+    });
 }
 void lcs_destroy(lcs_system* s) { delete s; }
 

@@ -56,6 +56,10 @@ public:
     // `device_ids` behind an lcm_group (one matcher + host thread per device, RCCL inside); every member function
     // behaves as with one device and returns the same results.  A C++ host needs no RCCL code of its own.
     LoopClosingSystem(double loop_threshold, int min_loop_gap, const std::vector<int>& device_ids);
+    // Rehearsal of the multi-device form on a box with ONE GPU: n_shards shards on device_id (lcm_group_create_loopback:
+    // the exchange steps are device-local copies).  Same results; exists for tests.
+    struct Loopback { int n_shards; int device_id; };
+    LoopClosingSystem(double loop_threshold, int min_loop_gap, Loopback rehearsal);
     ~LoopClosingSystem();
     LoopClosingSystem(const LoopClosingSystem&) = delete;
     LoopClosingSystem& operator=(const LoopClosingSystem&) = delete;
@@ -68,7 +72,10 @@ public:
     // (lcm_query_submit_batch), which is what keeps an MI355X busy when frames arrive faster than one launch per frame
     // can serve them.  Frames of one launch are not compared with each other, so a launch only ever
     // holds frames closer together than min_loop_gap (in ids, or in positions under setGapByPosition): the call cuts
-    // its input accordingly and is exact for any input.  Basic exception guarantee: frames that were stored stay.
+    // its input accordingly and is exact for any input.  Two micro-batches are in flight (batch k + 1 is submitted and
+    // its frames stored before batch k's records are collected), on one device, on one shard, or on every device of a
+    // group.  On an exception the frames whose loop check completed stay — with their closures — and every later frame
+    // is taken back from the host lists and from the device database(s).
     struct FrameInput { const uint8_t* descriptors; int rows; int num_keypoints; int frame_id; };
     void processFrames(const FrameInput* frames, int n);
 
@@ -120,8 +127,13 @@ private:
     int min_loop_gap_;                   // hpp:76
     int shard_rank_, shard_world_;
     bool gap_by_position_ = false;
-    // frames_[first, first + count): one micro-batch; `stored` / `closure_marks` report progress for the caller's rollback
-    void processBatch(size_t first, size_t count, size_t& stored, std::vector<size_t>& closure_marks);
+    // frames_[first, first + count) as one micro-batch: asynchronous submit (one launch per device), collect + loop test,
+    // store; drainBatch / truncateDevice serve the rollback when an error is on its way up
+    int submitBatch(size_t first, size_t count);
+    void collectBatch(int ticket, size_t first, size_t count);
+    void drainBatch(int ticket, size_t count) noexcept;
+    void storeFrame(size_t position);
+    void truncateDevice(size_t n_frames) noexcept;
     int keyOf(size_t position) const { return gap_by_position_ ? (int)position : frames_[position].id; }   // the matcher's id of a frame
 };
 

@@ -175,10 +175,12 @@ def test_search_larger_than_one_launch(pkg, oracle):
     p = pkg.default_params()
     p.min_gap = 30
 
-    def run(chunk, packed=0):
+    def run(chunk, packed=0, scratch_mb=0):
         with pkg.Matcher(p) as m:
             m.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, chunk)               # 0 = automatic
             m.set_tuning(pkg.capi.TUNE_PACKED, packed)
+            if scratch_mb:
+                m.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, scratch_mb)
             for f in range(fs.n_frames):
                 m.append(int(fs.ids[f]), fs.frame(f))
             n, offs = m.all_vs_all_plan()
@@ -197,11 +199,20 @@ def test_search_larger_than_one_launch(pkg, oracle):
     np.testing.assert_array_equal(one, many)
     np.testing.assert_array_equal(offs, offs2)
     # the automatic plan packs these 256-row frames eight to a 2048-row workgroup (half the lane slots of the 64 x 8
-    # shape are idle otherwise); more than 2^20 pairs -> two chunks of (score, fold) launches
-    packed, offs3, l3 = run(0, -1)
-    assert l3 == 4
+    # shape are idle otherwise); a chunk takes half of the per-row scratch (consecutive chunks alternate between the halves
+    # and between two streams): with 16 GiB a chunk holds 2^20 pairs -> three chunks of (score, fold) launches (the frames
+    # whose pairs fit one chunk form the first group, met in two slot ranges — the first one half-size, so that the two
+    # streams stay out of step —, the remaining frames the second); with the default 1 GiB 2^16 pairs -> seventeen or
+    # more; with 64 MiB 4096 pairs per chunk
+    packed, offs3, l3 = run(0, -1, 16384)
+    assert l3 == 6
     np.testing.assert_array_equal(one, packed)
     np.testing.assert_array_equal(offs, offs3)
+    for mb, lo in ((0, 2 * 17), (64, 2 * 264)):
+        packed, offs3, l3 = run(0, -1, mb)
+        assert l3 >= lo and l3 % 2 == 0, (mb, l3)
+        np.testing.assert_array_equal(one, packed)
+        np.testing.assert_array_equal(offs, offs3)
     rng = np.random.default_rng(3)
     qs = rng.integers(30, 1500, 300)
     ts = np.array([rng.integers(0, q - 29) for q in qs])

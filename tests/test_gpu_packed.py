@@ -209,7 +209,7 @@ def test_packed_equals_plain_on_random_shapes(matcher, oracle, pkg, seed):
         np.testing.assert_array_equal(res[1][1][k], wsums)
     finally:
         matcher.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, 0)
-        matcher.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, 8192)
+        matcher.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, 1024)          # the default
         matcher.set_tuning(pkg.capi.TUNE_PACKED, -1)
         matcher.set_params(min_gap=30)
         matcher.clear()

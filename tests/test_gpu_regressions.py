@@ -189,8 +189,9 @@ def test_snapshot_loader_survives_random_corruption(pkg, oracle, tmp_path):
 
 
 def test_packed_route_shrinks_its_scratch_when_the_device_is_full(pkg, oracle):
-    """The packed route's per-row scratch (3.9 GB for this search) does not fit next to a ballast that leaves ~2 GiB free:
-    the library halves its chunk size and plans again (LCM_ERR_OOM never reaches the caller), the records are the same."""
+    """The packed route's per-row scratch (1 GiB per chunk by default) does not fit next to a ballast that leaves ~700 MiB
+    free: the library halves its chunk size and plans again (LCM_ERR_OOM never reaches the caller), the records are the
+    same.  The shortage is not remembered: the next plan rebuild starts from the configured size again."""
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("no device visible to torch")
@@ -207,11 +208,16 @@ def test_packed_route_shrinks_its_scratch_when_the_device_is_full(pkg, oracle):
         m.set_tuning(pkg.capi.TUNE_PACKED, 0)
         m.all_vs_all(d, n); m.sync(); m.dev_download(d, ref)                 # plain route: no scratch
         m.set_tuning(pkg.capi.TUNE_PACKED, 1)
+        m.all_vs_all(d, n); m.sync()
+        normal = m.launch_info().launches                                    # chunks of half the configured 1 GiB
+        m.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, 1024)                  # drops the plan AND lets the scratch go below
+        m.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, 64); m.all_vs_all(d, n); m.sync()      # (a 64 MiB search frees the 1 GiB buffer)
+        m.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, 1024)
         free, _total = torch.cuda.mem_get_info(0)
         ballast = None
         try:
             try:
-                ballast = torch.empty(max(free - (2 << 30), 0), dtype=torch.uint8, device="cuda:0")
+                ballast = torch.empty(max(free - (700 << 20), 0), dtype=torch.uint8, device="cuda:0")
             except RuntimeError:
                 pytest.skip("could not fill the device (someone else holds memory)")
             got = np.zeros(n, pkg.capi.SCORE_DTYPE)
@@ -221,5 +227,11 @@ def test_packed_route_shrinks_its_scratch_when_the_device_is_full(pkg, oracle):
             del ballast
             torch.cuda.empty_cache()
         np.testing.assert_array_equal(got, ref)
-        assert info.route == pkg.capi.ROUTE_PACKED and info.launches >= 4      # several (score, fold) chunks now
+        assert info.route == pkg.capi.ROUTE_PACKED and info.launches > normal    # smaller chunks than configured, hence more of them
+        # memory is back: a rebuilt plan (any tuning change invalidates it) uses the configured 1 GiB again
+        m.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, 2)
+        got2 = np.zeros(n, pkg.capi.SCORE_DTYPE)
+        m.all_vs_all(d, n); m.sync(); m.dev_download(d, got2)
+        np.testing.assert_array_equal(got2, ref)
+        assert m.launch_info().launches == normal
         m.dev_free(d)
