@@ -663,6 +663,14 @@ class Group:
         _check(self._lib.lcm_group_online_stats_read(self._g, C.byref(st), 1 if reset else 0))
         return st
 
+    def shard_launch_info(self, rank: int) -> LaunchInfo:
+        """lcm_last_launch_info of shard `rank`'s own matcher (its last bulk launch: route, chunks, per-launch times)."""
+        h = _vp()
+        _check(self._lib.lcm_group_handle(self._g, rank, C.byref(h)))
+        info = LaunchInfo()
+        _check(self._lib.lcm_last_launch_info(h, C.byref(info)))
+        return info
+
     def info(self) -> GroupInfo:
         gi = GroupInfo()
         _check(self._lib.lcm_group_last_info(self._g, C.byref(gi)))

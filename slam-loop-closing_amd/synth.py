@@ -14,6 +14,16 @@ place-structured:
     own rows (ties and min_dist == 0);
   * with ragged=True the row count is uniform in [0.75 * max_desc, max_desc].
 
+  * with pool_k > 0 ("selective" variant) every frame also carries noisy copies of the SAME pool_k global descriptors
+    (each bit flipped with probability pool_flip) in place of as many outlier rows.  Without them two UNRELATED frames
+    have no close rows at all: their best distances are 88..107, 2 x min keeps every match, the similarity is 1.0 and
+    every pair "is a loop" (99.96 % of cfg4's pairs) — the README filter is vacuous on exactly the pairs that dominate.
+    With them every pair of frames shares pool_k true correspondences at distance ~46 +- 6 (pool_flip 0.10 on both
+    sides): min_dist ~ 34, the filter keeps those ~pool_k matches and rejects the 88+ ones, good_count ~ 30 < 50 and the
+    pair is NOT a loop; a revisit of a moderately noisy place (flip_p >= ~0.07: inlier distances concentrated well
+    above zero, so 2 x min covers most of them) keeps several hundred matches and IS one; a revisit of a very clean
+    place is not (its minimum is ~1, so "2 x min" keeps a handful of matches: the README rule's own blind spot).
+
 Everything is a pure function of (seed, n_frames, max_desc, ...): any rank can regenerate any frame.
 """
 from __future__ import annotations
@@ -55,8 +65,10 @@ def _flip(rng: np.random.Generator, rows: np.ndarray, p: float) -> np.ndarray:
 
 
 def make_frames(n_frames: int, max_desc: int, seed: int = BASE_SEED, *, inlier_frac: float = 0.4,
-                dup_frac: float = 0.01, ragged: bool = False, id_step: int = 1) -> FrameSet:
+                dup_frac: float = 0.01, ragged: bool = False, id_step: int = 1, pool_k: int = 0,
+                pool_flip: float = 0.10) -> FrameSet:
     n_places = max(1, n_frames // 4)
+    pool = np.random.default_rng([seed, 4]).integers(0, 256, size=(pool_k, DESC_BYTES), dtype=np.uint8) if pool_k > 0 else None
     rows = np.zeros((n_frames, max_desc, DESC_BYTES), np.uint8)
     counts = np.zeros(n_frames, np.int32)
     place_rng = [np.random.default_rng([seed, 1, p]) for p in range(n_places)]
@@ -78,6 +90,9 @@ def make_frames(n_frames: int, max_desc: int, seed: int = BASE_SEED, *, inlier_f
         pick = rng.permutation(max_desc)[:n_in]
         inl = _flip(rng, base(p)[pick], flip_p)
         out = rng.integers(0, 256, size=(n - n_in, DESC_BYTES), dtype=np.uint8)
+        if pool is not None and n - n_in > 0:
+            k = min(pool_k, n - n_in)
+            out[:k] = _flip(rng, pool[:k], pool_flip)
         fr = np.concatenate([inl, out], axis=0)
         if rng.random() < dup_frac and n >= 8:
             # planted exact duplicates: copies of base rows (distance 0 against the place) and of own rows (ties)
@@ -89,6 +104,13 @@ def make_frames(n_frames: int, max_desc: int, seed: int = BASE_SEED, *, inlier_f
         counts[f] = n
     ids = (np.arange(n_frames, dtype=np.int32) * id_step).astype(np.int32)
     return FrameSet(rows=rows, counts=counts, ids=ids, seed=seed)
+
+
+def make_frames_selective(n_frames: int, max_desc: int, seed: int = BASE_SEED, **kw) -> FrameSet:
+    """The variant on which the README filter is selective for unrelated pairs too (module docstring): 30 shared pool
+    descriptors per frame.  Loop candidates are then (a part of) the revisit pairs only."""
+    kw.setdefault("pool_k", 30)
+    return make_frames(n_frames, max_desc, seed, **kw)
 
 
 def uniform_frames(n_frames: int, max_desc: int, seed: int = BASE_SEED) -> FrameSet:
