@@ -78,7 +78,7 @@ def test_random_api_sequences_equal_oracle(pkg, oracle, tmp_path, seed):
         ran = {}
         for step in range(300):
             op = rng.choice(["append", "append", "append", "append_dev", "bulk", "bulk", "loops", "query", "submit", "batch",
-                             "collect", "detect", "match", "params", "variant", "tuning", "snapshot", "clear"])
+                             "collect", "detect", "match", "params", "variant", "tuning", "snapshot", "clear", "truncate"])
             op = str(op)
             ran[op] = ran.get(op, 0) + 1
             if op in ("append", "append_dev"):
@@ -94,6 +94,13 @@ def test_random_api_sequences_equal_oracle(pkg, oracle, tmp_path, seed):
             elif op == "clear" and rng.random() < 0.3:
                 collect_all()
                 m.clear(); model.ids.clear(); model.frames.clear()
+            elif op == "truncate" and len(model.frames) >= 2:
+                collect_all()                                         # (tickets submitted before a truncate are void)
+                keep = int(rng.integers(1, len(model.frames)))
+                m.truncate(keep)
+                del model.ids[keep:]; del model.frames[keep:]
+                next_id = max(next_id, model.ids[-1])
+                assert len(m) == keep
             elif op == "snapshot" and model.frames:
                 collect_all()
                 path = str(tmp_path / f"db_{seed}.bin")
@@ -115,6 +122,7 @@ def test_random_api_sequences_equal_oracle(pkg, oracle, tmp_path, seed):
                 m.set_tuning(pkg.capi.TUNE_ITEM_SLOTS, int(rng.choice([0, 1, 2, 5])))
                 m.set_tuning(pkg.capi.TUNE_ONLINE_SPLIT, int(rng.choice([-1, 0, 1, 2, 4, 16, 32])))
                 m.set_tuning(pkg.capi.TUNE_ONLINE_STREAMS, int(rng.choice([0, 1])))
+                m.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, int(rng.choice([1, 2, 1024])))     # 1 MiB: 64 pairs per chunk -> 2-D chunks
             elif op in ("bulk", "loops") and model.frames:
                 rows, counts = model.arrays()
                 pq, pt, offs = [], [], [0]
@@ -193,7 +201,8 @@ def test_random_group_sequences_equal_single_handle(pkg, oracle, world, seed):
     with pkg.Group(p0, n_devices=world, loopback_device=0) as g, pkg.Matcher(p0) as m:
         ran = {}
         for step in range(150):
-            op = str(rng.choice(["append", "append", "append", "append", "bulk", "bulk", "query", "batch", "detect", "params", "clear"]))
+            op = str(rng.choice(["append", "append", "append", "append", "bulk", "bulk", "argmin", "loops", "query", "batch", "async", "detect",
+                                 "params", "clear", "truncate"]))
             ran[op] = ran.get(op, 0) + 1
             if op == "append":
                 f = _frame(rng, alphabet)
@@ -202,6 +211,49 @@ def test_random_group_sequences_equal_single_handle(pkg, oracle, world, seed):
                 model.ids.append(next_id); model.frames.append(f)
             elif op == "clear" and rng.random() < 0.25:
                 g.clear(); m.clear(); model.ids.clear(); model.frames.clear()
+            elif op == "truncate" and len(model.frames) >= 2:
+                keep = int(rng.integers(1, len(model.frames)))
+                g.truncate(keep); m.truncate(keep)
+                del model.ids[keep:]; del model.frames[keep:]
+                next_id = max(next_id, model.ids[-1])
+                assert len(g) == keep
+            elif op in ("argmin", "loops") and model.frames:
+                n, moffs = m.all_vs_all_plan()
+                if op == "argmin":
+                    gs, gi, goffs = g.all_vs_all_argmin()
+                    assert len(gs) == n
+                    if n:
+                        d, ds = m.dev_alloc(n * 8), m.dev_alloc(n * 4)
+                        ss, si = np.zeros(n, pkg.capi.SCORE_DTYPE), np.zeros(n, np.uint32)
+                        m.all_vs_all_argmin(d, n, ds); m.sync(); m.dev_download(d, ss); m.dev_download(ds, si)
+                        m.dev_free(d); m.dev_free(ds)
+                        np.testing.assert_array_equal(gs, ss, err_msg=f"step {step} world {world}")
+                        np.testing.assert_array_equal(gi, si, err_msg=f"step {step} world {world} (index checksums)")
+                elif n:
+                    a, na = g.all_vs_all_loops(cap=n)
+                    b, nb = m.all_vs_all_loops(cap=n)
+                    assert na == nb == n
+                    np.testing.assert_array_equal(a, b, err_msg=f"step {step} world {world}")
+            elif op == "async":
+                # several group tickets in flight with appends between submit and collect, collected in submit order
+                tickets = []
+                for _ in range(int(rng.integers(1, 4))):
+                    k = int(rng.integers(1, 5))
+                    qs = [_frame(rng, alphabet) for _ in range(k)]
+                    qids = [next_id + 1 + j for j in range(k)]
+                    tg = g.query_submit_batch(qs, qids)
+                    tm = m.query_submit_batch(qs, qids)
+                    tickets.append((tg, tm, k))
+                    if rng.random() < 0.6:
+                        f = _frame(rng, alphabet)
+                        next_id += int(rng.integers(1, 4))
+                        g.append(next_id, f); m.append(next_id, f)
+                        model.ids.append(next_id); model.frames.append(f)
+                for tg, tm, k in tickets:
+                    b, ob = m.query_collect_batch(tm)
+                    a, oa = g.query_collect_batch(tg, max(len(model.frames), 1) * k, k)
+                    np.testing.assert_array_equal(oa[: k + 1], ob)
+                    np.testing.assert_array_equal(a, b, err_msg=f"step {step} world {world}")
             elif op == "params":
                 gap = int(rng.integers(0, 5))
                 p = pkg.default_params()
@@ -247,4 +299,4 @@ def test_random_group_sequences_equal_single_handle(pkg, oracle, world, seed):
                 b = m.detect_loops(qid, q)
                 for f in ("matched_frame_id", "num_matches", "similarity_score"):
                     np.testing.assert_array_equal(a[f], b[f], err_msg=f"step {step}")
-        assert all(ran.get(k, 0) > 0 for k in ("append", "bulk", "query", "batch", "detect", "params"))
+        assert all(ran.get(k, 0) > 0 for k in ("append", "bulk", "argmin", "loops", "query", "batch", "async", "detect", "params"))

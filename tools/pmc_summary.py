@@ -9,7 +9,7 @@ import sys
 
 prof, out_path = sys.argv[1], sys.argv[2]
 kernels = {}
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "valu"):
     path = os.path.join(prof, sub, "p_counter_collection.csv")
     if not os.path.exists(path):
         continue
@@ -25,7 +25,7 @@ for k in kernels.values():
         c["per_launch"] = c["sum"] / max(c["dispatches"], 1)
 out = {
     "command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-extras "
-               "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE)",
+               "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* + GRBM_GUI_ACTIVE | SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_* SQ_WAVE_CYCLES)",
     "units": "FETCH_SIZE / WRITE_SIZE in KB (TCC_EA0 requests x 64 B / 1024), others raw counts; per_launch = sum / dispatches",
     "kernels": kernels,
 }
