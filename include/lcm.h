@@ -30,7 +30,9 @@
  *     boundary; lcm_last_error() gives the message of the calling thread's last failure.
  *   - there is NO CPU fallback: without a usable HIP device lcm_create fails with
  *     LCM_ERR_NO_DEVICE.  The CPU restatement under oracle/ is test infrastructure only.
- *   - a handle is thread-compatible (one caller at a time).
+ *   - a handle is thread-compatible (one caller at a time).  A call leaves the calling thread's current HIP device set to
+ *     the handle's device (lcm_group_* calls: to one of the group's devices); callers that run their own HIP work on
+ *     another device set it again afterwards.
  *   - sizes: a frame holds up to 65535 descriptor rows, as stored ("train") frame and as query frame alike (ORB's
  *     nfeatures is the caller's choice; the reference uses 2000).  Query frames above 2048 rows take the packed bulk
  *     route (see lcm_route); with cross_check != 0, or with LCM_TUNE_PACKED = 0, query frames are limited to 2048

@@ -486,6 +486,7 @@ int lcm_loop_test(const lcm_params* p, const lcm_score* s, int n_query_kp, int n
 int lcm_last_launch_info(const lcm_handle* hc, lcm_launch_info* info) {
     lcm_handle* h = const_cast<lcm_handle*>(hc);
     if (!h || !info) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    if (h->info_pending || h->aux_pending) { const int rc = set_device(h); if (rc) return rc; }     // its events live on its device
     if (h->info_pending) {
         HIP_TRY(hipEventSynchronize(h->ev_stop));
         float ms = 0.f;

@@ -437,6 +437,7 @@ int loop_test_device(lcm_handle* h, const void* d_scores, size_t n_pairs, const 
                      size_t cap, size_t* n_found) {
     *n_found = 0;
     if (n_pairs == 0) return LCM_OK;
+    { const int rc0 = set_device(h); if (rc0) return rc0; }      // (called from a group's per-device host threads too)
     // metadata the loop test needs, as one upload: offsets | q_ids | q_kp | db_ids | db_kp
     std::vector<int32_t> meta((size_t)(n_q + 1) + 2 * (size_t)n_q + 2 * (size_t)n_db);
     int32_t* m_off = meta.data();
