@@ -160,8 +160,9 @@ def roofline_from_launches(pkg, infos, n_desc, argmin, traffic=None, traffic_sou
     steps of ONE device.  A packed bulk search runs as several (score, fold) chunk launches; consecutive chunks sit on
     two streams, so two score launches are in flight at any time.  `kernel_ms` is the dominant kernel's AVERAGE
     LAUNCH DURATION from events around every score launch on its own stream (what rocprofv3 --kernel-trace --stats
-    reports as that kernel's average), `achieved` = algorithmic bytes per launch x launches in flight / that duration
-    = algorithmic bytes per step / the step's kernel span (the cross-check printed beside it)."""
+    reports as that kernel's average), `achieved` = algorithmic bytes per launch / that duration (the contract's formula,
+    to the letter: ONE launch's own rate), `achieved_chip` = x launches in flight = what the chip moves while they run,
+    `achieved_per_step` = algorithmic bytes per step / the step's kernel span (the cross-check)."""
     li = infos[-1]
     packed = (li.route == pkg.capi.ROUTE_PACKED)
     step_ms = float(np.mean([x.kernel_ms for x in infos]))
@@ -177,7 +178,7 @@ def roofline_from_launches(pkg, infos, n_desc, argmin, traffic=None, traffic_sou
         fold_ms = None
     bytes_step = int(li.algo_bytes)
     bytes_launch = bytes_step / n_launch
-    achieved = bytes_launch * in_flight / (launch_ms * 1e-3) / 1e9
+    achieved = bytes_launch / (launch_ms * 1e-3) / 1e9
     per_step = bytes_step / (step_ms * 1e-3) / 1e9
     kern_rate = int(li.distances) / (step_ms * 1e-3)
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -188,12 +189,16 @@ def roofline_from_launches(pkg, infos, n_desc, argmin, traffic=None, traffic_sou
                       else "one workgroup per (query frame, run of stored frames)"),
             "kernel_ms": launch_ms, "launches_per_step": n_launch, "launches_in_flight": in_flight,
             "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_step": bytes_step,
-            "step_kernel_ms": step_ms, "achieved_per_step": per_step, "fold_kernels_ms_per_step": fold_ms,
+            "step_kernel_ms": step_ms, "achieved_chip": achieved * in_flight, "achieved_per_step": per_step,
+            "fold_kernels_ms_per_step": fold_ms,
             "note": "this path is VALU-bound by ~200x (0.016 algorithmic bytes per distance); see roofline_valu.  kernel_ms = "
                     "average duration of ONE score launch (HIP events around each on its stream; with 2 launches in flight "
-                    "they overlap pairwise, so the sum of the durations is ~2 x step_kernel_ms); achieved = bytes per launch x "
-                    "launches in flight / kernel_ms; achieved_per_step = bytes per step / step_kernel_ms (all score + fold "
-                    "kernels of a step, device clock).  traffic = L2-to-fabric bytes incl. Infinity-Cache hits"}
+                    "they overlap pairwise, so the launches' durations sum to more than step_kernel_ms); achieved = bytes per "
+                    "launch / kernel_ms = one launch's own rate; achieved_chip = achieved x launches in flight; "
+                    "achieved_per_step = bytes per step / step_kernel_ms (all score + fold kernels of a step, device clock): "
+                    "the rate to compare across rounds.  traffic = L2-to-fabric bytes per score launch incl. Infinity-Cache "
+                    "hits; fold_kernels_ms_per_step sums the folds' own durations, which include waiting for a free CU behind "
+                    "the other stream's score kernel"}
     valu = {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
             "frac": kern_rate / VALU_PEAK_DIST_PER_S, "nominal_peak": VALU_NOMINAL_DIST_PER_S,
             "nominal_frac": kern_rate / VALU_NOMINAL_DIST_PER_S,

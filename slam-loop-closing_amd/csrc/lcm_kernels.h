@@ -118,12 +118,18 @@ struct PairDesc {
     uint32_t out_row0;           // first row of this pair in the folded key array
 };
 struct FoldArgs {
-    const uint32_t* seg_keys;    // per item: MAX_FUSED_QUERY_ROWS keys
+    const uint32_t* seg_keys;    // per item: chunk_rows keys
+    uint32_t        chunk_rows;  // query rows per item: 2048 (throughput shape) or 512 (latency shape); 0 means 2048
     const PairDesc* pairs;
     uint32_t*       final_keys;
     uint32_t        n_pairs;
 };
 hipError_t launch_fold_pair_keys(const FoldArgs& a, uint32_t max_nq, hipStream_t st);
+// Pair mode, first step, LATENCY shape: items of <= 512 query rows on 256-thread workgroups of 2 rows per lane.  One
+// matchFeatures call is a few hundred thousand distances per wave whatever the shape, and a wave alone on its SIMD issues
+// one VALU instruction per ~8 cycles: what shortens the call is MORE waves with less work each, not fewer instructions
+// (2000 x 2000: 252 workgroups x 4 waves x 64 distances per lane instead of 63 x 4 x 256).
+hipError_t launch_score_pairs_small(const ScoreArgs& a, uint32_t n_items, hipStream_t st);
 
 // On-device loop test over a finished score array (BASELINE.json configs[3] "fused on-device filter + loop test"):
 // pair p belongs to query frame c = upper_bound(offsets, p) - 1 and stored slot p - offsets[c]; a candidate is

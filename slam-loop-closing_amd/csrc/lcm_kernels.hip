@@ -646,10 +646,11 @@ __global__ __launch_bounds__(256) void k_fold_pair_keys(FoldArgs a) {
     const PairDesc p = a.pairs[blockIdx.y];
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= p.nq) return;
-    const uint32_t c = r / MAX_FUSED_QUERY_ROWS, lr = r % MAX_FUSED_QUERY_ROWS;
-    const uint32_t* src = a.seg_keys + ((size_t)p.first_item + (size_t)c * p.n_seg) * MAX_FUSED_QUERY_ROWS + lr;
+    const uint32_t CR = a.chunk_rows ? a.chunk_rows : (uint32_t)MAX_FUSED_QUERY_ROWS;
+    const uint32_t c = r / CR, lr = r % CR;
+    const uint32_t* src = a.seg_keys + ((size_t)p.first_item + (size_t)c * p.n_seg) * CR + lr;
     uint32_t best = 0xFFFFFFFFu;
-    for (uint32_t g = 0; g < p.n_seg; ++g) best = min(best, src[(size_t)g * MAX_FUSED_QUERY_ROWS] + g * p.seg_rows);
+    for (uint32_t g = 0; g < p.n_seg; ++g) best = min(best, src[(size_t)g * CR] + g * p.seg_rows);
     a.final_keys[p.out_row0 + r] = best;
 }
 
@@ -675,6 +676,10 @@ hipError_t launch_score_packed(const ScoreArgs& a, uint32_t n_items, bool argmin
     if (argmin) hipLaunchKernelGGL((k_score_rowlane<256, 8, 1, false, true>), dim3(n_items), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_score_rowlane<256, 8, 0, false, true>), dim3(n_items), dim3(256), 0, st, a);
     return hipGetLastError();
+}
+
+hipError_t launch_score_pairs_small(const ScoreArgs& a, uint32_t n_items, hipStream_t st) {
+    return launch_rowlane<256, 2>(a, n_items, true, true, st);
 }
 
 // Split-mode launch: 256-thread workgroups holding `qpt` query rows per lane, writing best distances to a.keys.

@@ -28,8 +28,14 @@ struct PairJob { uint32_t q_row; int nq; uint32_t t_row; int nt; };
 // precede the items / descriptors this function appends, and the whole block goes up in ONE hipMemcpyAsync.
 static int run_pair_jobs(lcm_handle* h, const uint8_t* d_q_base, const uint8_t* d_t_base, bool q_in_stage, bool t_in_stage,
                          size_t stage_bytes, const std::vector<PairJob>& jobs, const uint32_t** keys_out, std::vector<size_t>& row0) {
-    const int CH = lcm::MAX_FUSED_QUERY_ROWS;
     const size_t P = jobs.size();
+    // Work-item shape.  Throughput shape: query chunks of 2048 rows (8 per lane).  LATENCY shape, for calls of up to 64 M
+    // distances (one matchFeatures of 2000 x 2000 is 4 M): chunks of 512 rows (2 per lane) — four times the waves with a
+    // quarter of the work each (lcm_kernels.h, launch_score_pairs_small).
+    uint64_t call_distances = 0;
+    for (const PairJob& jb : jobs) call_distances += (uint64_t)jb.nq * (uint64_t)jb.nt;
+    const bool small = call_distances <= (64ull << 20);
+    const int CH = small ? 512 : lcm::MAX_FUSED_QUERY_ROWS;
     row0.assign(P + 1, 0);
     size_t n_items = 0, total_rows = 0;
     int max_nq = 0;
@@ -89,9 +95,19 @@ static int run_pair_jobs(lcm_handle* h, const uint8_t* d_q_base, const uint8_t* 
     a.pair_items = reinterpret_cast<const lcm::PairItem*>(h->d_pair_stage + off_items);
     a.scores = nullptr; a.keys = h->d_keys; a.keys_stride = CH;
     a.ratio = h->params.ratio; a.dist_floor = h->params.dist_floor;
-    rc = launch_and_time(h, a, (uint32_t)n_items, max_nq > CH ? CH : max_nq, true); if (rc) return rc;
+    if (small) {
+        HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+        const hipError_t e1 = lcm::launch_score_pairs_small(a, (uint32_t)n_items, h->stream);
+        if (e1 != hipSuccess) return fail(LCM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e1));
+        HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+        h->info_pending = true;
+        h->info.workgroups = (uint32_t)n_items; h->info.route = LCM_ROUTE_PLAIN;
+    } else {
+        rc = launch_and_time(h, a, (uint32_t)n_items, max_nq > CH ? CH : max_nq, true); if (rc) return rc;
+    }
     lcm::FoldArgs f{};
     f.seg_keys = h->d_keys;
+    f.chunk_rows = (uint32_t)CH;
     f.pairs = reinterpret_cast<const lcm::PairDesc*>(h->d_pair_stage + off_descs);
     f.final_keys = h->d_keys + n_items * (size_t)CH;
     f.n_pairs = (uint32_t)P;
