@@ -5,7 +5,7 @@
  * Part 1 (golden): byte-at-a-time, single-threaded, written for auditability, not speed.
  * Part 2 (baseline): the same results with 64-bit popcount or AVX-512 VPOPCNTDQ and pthreads over pairs;
  *                    it stands in for cv::BFMatcher's parallel_for_ + SIMD normHamming when bench.py
- *                    reports a CPU baseline.  tests/test_oracle_fast.py checks Part 2 == Part 1.
+ *                    reports a CPU baseline.  tests/test_oracle_numpy.py and tests/test_golden.py check Part 2 == Part 1.
  */
 #define _GNU_SOURCE
 #include "lcm_oracle.h"

@@ -109,7 +109,10 @@ static int run_pair_jobs(lcm_handle* h, const uint8_t* d_q_base, const uint8_t* 
     f.seg_keys = h->d_keys;
     f.chunk_rows = (uint32_t)CH;
     f.pairs = reinterpret_cast<const lcm::PairDesc*>(h->d_pair_stage + off_descs);
-    f.final_keys = h->d_keys + n_items * (size_t)CH;
+    // Latency shape: the fold kernel writes the folded keys STRAIGHT into the pinned host buffer (mapped into the device's
+    // address space; 4 bytes per query row over PCIe), so no device-to-host copy packet follows it: the stream's
+    // synchronisation below is also the hand-over.  Throughput shape: device buffer + one copy.
+    f.final_keys = small ? h->h_final_keys : h->d_keys + n_items * (size_t)CH;
     f.n_pairs = (uint32_t)P;
     hipError_t e = lcm::launch_fold_pair_keys(f, (uint32_t)max_nq, h->stream);
     if (e != hipSuccess) return fail(LCM_ERR_HIP, "fold kernel launch failed: %s", hipGetErrorString(e));
@@ -119,7 +122,7 @@ static int run_pair_jobs(lcm_handle* h, const uint8_t* d_q_base, const uint8_t* 
         h->info.distances += (uint64_t)jb.nq * (uint64_t)jb.nt;
         h->info.algo_bytes += (uint64_t)jb.nt * 32 + (uint64_t)jb.nq * 32 + 8;
     }
-    HIP_TRY(hipMemcpyAsync(h->h_final_keys, f.final_keys, sizeof(uint32_t) * total_rows, hipMemcpyDeviceToHost, h->stream));
+    if (!small) HIP_TRY(hipMemcpyAsync(h->h_final_keys, f.final_keys, sizeof(uint32_t) * total_rows, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     *keys_out = h->h_final_keys;
     return LCM_OK;
