@@ -506,8 +506,9 @@ def group_mode(args, pkg, torch, entry):
     fs = pkg.synth.make_frames(n_frames, n_desc, seed=seed)
     p = pkg.default_params()
     p.min_gap = args.gap
-    kw = dict(n_devices=W, loopback_device=0) if loopback else dict(n_devices=W)
+    kw = dict(n_devices=W, loopback_device=0) if loopback else dict(n_devices=W, peer_copies=bool(args.peer_copies))
     g = pkg.Group(p, **kw)
+    transport = g.transport
     g.set_tuning(pkg.capi.TUNE_PACKED, args.packed)
     if args.mode == "stream":
         return group_stream_mode(args, pkg, entry, g, fs, W, loopback, wl_desc, seed)
@@ -587,7 +588,7 @@ def group_mode(args, pkg, torch, entry):
                    "form": "one process, lcm_group over %d %s" % (W, "shards on ONE device (loopback rehearsal)" if loopback else "device(s)"),
                    "api": "lcm_group_all_vs_all_argmin" if argmin_api else "lcm_group_all_vs_all",
                    "outputs": "merged score records on the host" + (" + merged per-pair index checksums" if argmin_api else "")},
-        "group": {"n_devices": int(gi.n_devices), "rccl_ranks": int(gi.rccl_ranks), "loopback": bool(gi.loopback),
+        "group": {"n_devices": int(gi.n_devices), "rccl_ranks": int(gi.rccl_ranks), "loopback": bool(gi.loopback), "transport": transport,
                   "kernel_ms_max": gi.kernel_ms_max, "kernel_ms_per_device": [gi.kernel_ms[r] for r in range(W)],
                   "pairs_per_device": [int(gi.shard_pairs[r]) for r in range(W)],
                   "gather_merge_ms": gi.gather_merge_ms, "download_ms": gi.download_ms,
@@ -724,6 +725,8 @@ def main():
                     "same value and bytes as the plain line")
     ap.add_argument("--loopback", action="store_true", help="rehearse --gpus N as N shards on ONE device (lcm_group_create_loopback): the "
                     "N-device code path end to end on a one-GPU box; NOT a scaling measurement")
+    ap.add_argument("--peer-copies", action="store_true", help="--gpus N in one process: exchange steps as device-to-device copies over xGMI "
+                    "(lcm_group_create_peer) instead of RCCL — what lcm_group_create falls back to when no communicator can be created")
     ap.add_argument("--force-dist", action="store_true", help="exercise the process-per-GPU code path (process group, all-gather) even at world size 1")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU rehearsal of the process-per-GPU path)")
     args = ap.parse_args()

@@ -318,6 +318,12 @@ typedef struct lcm_group_info {
 } lcm_group_info;
 /* device_ids == NULL: devices 0 .. n_devices-1.  n_devices <= 8. */
 LCM_API int  lcm_group_create(const lcm_params* params, int n_devices, const int* device_ids, lcm_group** out);
+/* The same group with its two exchange steps as device-to-device copies over xGMI (hipMemcpyAsync between the devices'
+ * buffers, peer access enabled where available) instead of RCCL calls.  lcm_group_create falls back to this form by
+ * itself when the RCCL communicator cannot be created; lcm_group_transport says which one a group uses ("rccl",
+ * "peer copies (...)", "loopback (...)").  Results are identical. */
+LCM_API int  lcm_group_create_peer(const lcm_params* params, int n_devices, const int* device_ids, lcm_group** out);
+LCM_API const char* lcm_group_transport(const lcm_group* g);
 /* Rehearsal form for boxes with ONE GPU: n_shards matchers on device_id, the two exchange steps as device-local copies
  * instead of RCCL calls.  Same results as any other group; exists so that the multi-device index arithmetic (cyclic
  * ownership, rank-major query buffer, gatherv offsets, device merge) is exercised for W > 1 where no second GPU is. */

@@ -131,6 +131,8 @@ _SIGNATURES = {
     "lcm_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "lcm_group_create": (C.c_int, [C.POINTER(Params), C.c_int, _i32p, C.POINTER(_vp)]),
     "lcm_group_create_loopback": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lcm_group_create_peer": (C.c_int, [C.POINTER(Params), C.c_int, _i32p, C.POINTER(_vp)]),
+    "lcm_group_transport": (C.c_char_p, [_vp]),
     "lcm_group_destroy": (None, [_vp]),
     "lcm_group_size": (C.c_int, [_vp]),
     "lcm_group_db_size": (C.c_int, [_vp]),
@@ -548,8 +550,9 @@ class Group:
     """lcm_group: one process, W devices, stored frames sharded cyclically by arrival position, RCCL inside."""
 
     def __init__(self, params: Optional[Params] = None, n_devices: int = 1, device_ids: Optional[Sequence[int]] = None,
-                 loopback_device: Optional[int] = None):
-        """loopback_device: rehearsal form — n_devices shards on that ONE device, exchange steps as device-local copies."""
+                 loopback_device: Optional[int] = None, peer_copies: bool = False):
+        """loopback_device: rehearsal form — n_devices shards on that ONE device, exchange steps as device-local copies.
+        peer_copies: a real group whose exchange steps are device-to-device copies instead of RCCL calls."""
         self._lib = load_library()
         self._g = _vp()
         p = params if params is not None else default_params()
@@ -557,8 +560,12 @@ class Group:
             _check(self._lib.lcm_group_create_loopback(C.byref(p), n_devices, loopback_device, C.byref(self._g)))
             return
         ids = None if device_ids is None else np.ascontiguousarray(device_ids, np.int32)
-        _check(self._lib.lcm_group_create(C.byref(p), n_devices, None if ids is None else ids.ctypes.data_as(_i32p),
-                                          C.byref(self._g)))
+        create = self._lib.lcm_group_create_peer if peer_copies else self._lib.lcm_group_create
+        _check(create(C.byref(p), n_devices, None if ids is None else ids.ctypes.data_as(_i32p), C.byref(self._g)))
+
+    @property
+    def transport(self) -> str:
+        return self._lib.lcm_group_transport(self._g).decode()
 
     def close(self):
         if getattr(self, "_g", None):

@@ -101,6 +101,11 @@ struct lcm_group {
     // are device-local copies instead of RCCL calls — every index computation of the multi-device path (cyclic
     // ownership, rank-major query buffer, gatherv offsets, merge) runs for W > 1 on a box with a single GPU.
     bool loopback = false;
+    // Exchange steps as device-to-device copies (hipMemcpyAsync between the devices' arenas: xGMI peer copies) instead of
+    // RCCL calls: always in the loopback form; in a real group when the caller asked for it (lcm_group_create_peer) or
+    // when the RCCL communicator could not be created (the reason is kept in rccl_error).
+    bool copies = false;
+    std::string rccl_error;
     lcm_params params{};
     std::vector<int> devices;
     std::vector<lcm_handle*> h;
@@ -291,7 +296,7 @@ int lcm_merge_shard_scores(const lcm_score* const* shard_scores, const size_t* s
 }
 
 
-static int group_create(const lcm_params* params, int n_devices, const int* device_ids, bool loopback, int loop_device, lcm_group** out) {
+static int group_create(const lcm_params* params, int n_devices, const int* device_ids, bool loopback, int loop_device, bool peer_copies, lcm_group** out) {
     if (!out) return fail(LCM_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (n_devices < 1 || n_devices > MAX_WORLD) return fail(LCM_ERR_INVALID_ARG, "n_devices must be 1..%d", MAX_WORLD);
@@ -305,6 +310,7 @@ static int group_create(const lcm_params* params, int n_devices, const int* devi
         auto bail = [&](int rc) { const std::string why = lcm::last_error(); lcm_group_destroy(g); lcm::last_error() = why; return rc; };
         g->world = n_devices;
         g->loopback = loopback;
+        g->copies = loopback || peer_copies;
         lcm_params_default(&g->params);
         if (params) g->params = *params;
         for (int r = 0; r < n_devices; ++r) {
@@ -323,10 +329,32 @@ static int group_create(const lcm_params* params, int n_devices, const int* devi
             const int rc = lcm_create(&g->params, g->devices[(size_t)r], nullptr, &g->h[(size_t)r]);
             if (rc) return bail(rc);
         }
-        if (!loopback) {
+        if (!g->copies) {
             g->comms.assign(W, nullptr);
             ncclResult_t nr = ncclCommInitAll(g->comms.data(), n_devices, g->devices.data());
-            if (nr != ncclSuccess) { g->comms.clear(); return bail(fail(LCM_ERR_HIP, "ncclCommInitAll failed: %s", ncclGetErrorString(nr))); }
+            if (nr != ncclSuccess) {
+                // no communicator: the group still works, its two exchange steps fall back to peer copies
+                g->comms.clear();
+                g->copies = true;
+                g->rccl_error = ncclGetErrorString(nr);
+                (void)hipGetLastError();
+            }
+        }
+        if (g->copies && !loopback && n_devices > 1) {
+            // let every device of the group reach every other one's memory directly (xGMI); where peer access is not
+            // available the runtime stages the copies through the host — slower, still correct
+            for (int r = 0; r < n_devices; ++r) {
+                if (hipSetDevice(g->devices[(size_t)r]) != hipSuccess) return bail(fail(LCM_ERR_HIP, "hipSetDevice(%d) failed", g->devices[(size_t)r]));
+                for (int q = 0; q < n_devices; ++q) {
+                    if (q == r) continue;
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, g->devices[(size_t)r], g->devices[(size_t)q]) == hipSuccess && can) {
+                        const hipError_t pe = hipDeviceEnablePeerAccess(g->devices[(size_t)q], 0);
+                        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                        else (void)hipGetLastError();
+                    }
+                }
+            }
         }
         if (hipSetDevice(g->devices[0]) != hipSuccess || hipEventCreate(&g->ev0) != hipSuccess ||
             hipEventCreate(&g->ev1) != hipSuccess || hipEventCreate(&g->ev2) != hipSuccess ||
@@ -339,11 +367,22 @@ static int group_create(const lcm_params* params, int n_devices, const int* devi
 }
 
 int lcm_group_create(const lcm_params* params, int n_devices, const int* device_ids, lcm_group** out) {
-    return group_create(params, n_devices, device_ids, false, 0, out);
+    return group_create(params, n_devices, device_ids, false, 0, false, out);
+}
+
+int lcm_group_create_peer(const lcm_params* params, int n_devices, const int* device_ids, lcm_group** out) {
+    return group_create(params, n_devices, device_ids, false, 0, true, out);
 }
 
 int lcm_group_create_loopback(const lcm_params* params, int n_shards, int device_id, lcm_group** out) {
-    return group_create(params, n_shards, nullptr, true, device_id, out);
+    return group_create(params, n_shards, nullptr, true, device_id, false, out);
+}
+
+const char* lcm_group_transport(const lcm_group* g) {
+    if (!g) return "";
+    if (g->loopback) return "loopback (device-local copies)";
+    if (!g->copies) return "rccl";
+    return g->rccl_error.empty() ? "peer copies (requested)" : "peer copies (ncclCommInitAll failed)";
 }
 
 void lcm_group_destroy(lcm_group* g) {
@@ -472,7 +511,7 @@ int group_search(lcm_group* g, SearchMode mode, lcm_score* out_scores, uint32_t*
     g->info.n_devices = W;
     g->info.loopback = g->loopback ? 1 : 0;
     g->info.pairs = total;
-    if (!g->loopback && !g->comms.empty()) { int cnt = 0; if (ncclCommCount(g->comms[0], &cnt) == ncclSuccess) g->info.rccl_ranks = cnt; }
+    if (!g->copies && !g->comms.empty()) { int cnt = 0; if (ncclCommCount(g->comms[0], &cnt) == ncclSuccess) g->info.rccl_ranks = cnt; }
     if (total == 0) return LCM_OK;
 
     // ---- 1. equal shard geometry on every device, then — only if the database changed since the last search — the
@@ -497,15 +536,18 @@ int group_search(lcm_group* g, SearchMode mode, lcm_score* out_scores, uint32_t*
             rc = ensure_dev(g->d_qcounts[(size_t)r], g->d_qcounts_n[(size_t)r], (size_t)shard_cap * (size_t)W); if (rc) return rc;
         }
         int rc = set_dev(g, 0); if (rc) return rc;
-        if (g->loopback) {
-            // what ncclAllGather delivers, as device-local copies (every shard's appends have landed: host wait)
+        if (g->copies) {
+            // what ncclAllGather delivers, as device-to-device copies (every shard's appends have landed: host wait)
             for (int r = 0; r < W; ++r) { rc = lcm_sync(g->h[(size_t)r]); if (rc) return rc; }
             HIP_TRY(hipEventRecord(g->evg0, g->h[0]->stream));
-            for (int r = 0; r < W; ++r)
+            for (int r = 0; r < W; ++r) {
+                rc = set_dev(g, r); if (rc) return rc;           // the copies INTO device r are enqueued on its stream
                 for (int s = 0; s < W; ++s) {
                     HIP_TRY(hipMemcpyAsync(g->d_qrows[(size_t)r] + (size_t)s * shard_bytes, g->h[(size_t)s]->d_rows, shard_bytes, hipMemcpyDeviceToDevice, g->h[(size_t)r]->stream));
                     HIP_TRY(hipMemcpyAsync(g->d_qcounts[(size_t)r] + (size_t)s * (size_t)shard_cap, g->h[(size_t)s]->d_counts, sizeof(int32_t) * (size_t)shard_cap, hipMemcpyDeviceToDevice, g->h[(size_t)r]->stream));
                 }
+            }
+            rc = set_dev(g, 0); if (rc) return rc;
             HIP_TRY(hipEventRecord(g->evg1, g->h[0]->stream));
         } else {
             // every device's stream first waits (on the device, no host wait) for the appends of its own shard
@@ -634,7 +676,7 @@ int group_search(lcm_group* g, SearchMode mode, lcm_score* out_scores, uint32_t*
     HIP_TRY(hipEventRecord(g->ev0, g->h[0]->stream));
     std::vector<uint32_t> shard_base((size_t)W + 1, 0);
     for (int r = 0; r < W; ++r) shard_base[(size_t)r + 1] = shard_base[(size_t)r] + offr[(size_t)r][(size_t)N];
-    if (W > 1 && g->loopback) {
+    if (W > 1 && g->copies) {
         // what the grouped ncclSend / ncclRecv delivers: each shard's records behind device 0's
         for (int r = 1; r < W; ++r) {
             const size_t n = (size_t)offr[(size_t)r][(size_t)N];

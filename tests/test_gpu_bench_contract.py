@@ -114,7 +114,7 @@ def test_force_group_reproduces_the_plain_line():
     assert db["equals_single_handle"] == {"records": True, "index_checksums": True}
     assert db["cpu_baseline"]["gpu_vs_cpu_sample_mismatches"] == 0 and db["cpu_baseline"]["gpu_vs_cpu_index_checksum_mismatches"] == 0
     g = db["group"]
-    assert g["n_devices"] == 1 and g["rccl_ranks"] == 1 and not g["loopback"] and g["arena_allgather"]["timed_steps_skipped_it"]
+    assert g["n_devices"] == 1 and g["rccl_ranks"] == 1 and g["transport"] == "rccl" and not g["loopback"] and g["arena_allgather"]["timed_steps_skipped_it"]
     assert g["arena_allgather"]["first_search_bytes_per_device"] == 200 * 2000 * 32
     assert len(g["kernel_ms_per_device"]) == 1 and g["kernel_ms_max"] > 0
     # a 17 K-pair search is a few ms: launch-bound, so only the order of magnitude is comparable here; the 1 % agreement

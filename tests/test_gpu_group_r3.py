@@ -105,6 +105,25 @@ def test_group_argmin_and_loops_equal_single_handle(pkg, oracle, world):
         np.testing.assert_array_equal(g.all_vs_all()[0], np.concatenate([sc, m.query_scores(extra.frame(0), 20000)[0]]))
 
 
+def test_group_transports_of_one_device(pkg):
+    """which exchange transport a group uses is observable; the peer-copy form (the fallback when no RCCL communicator can be
+    created) gives the same bytes"""
+    fs = pkg.synth.make_frames(40, 600, seed=21, ragged=True, dup_frac=0.2)
+    p = pkg.default_params()
+    p.min_gap = 2
+    res = {}
+    for name, kw in (("rccl", dict(n_devices=1)), ("peer", dict(n_devices=1, peer_copies=True)), ("loop", dict(n_devices=2, loopback_device=0))):
+        with pkg.Group(p, **kw) as g:
+            fill(fs, g)
+            res[name] = (g.all_vs_all_argmin()[:2], g.transport, g.info().rccl_ranks)
+    assert res["rccl"][1] == "rccl" and res["rccl"][2] == 1
+    assert res["peer"][1] == "peer copies (requested)" and res["peer"][2] == 0
+    assert res["loop"][1].startswith("loopback") and res["loop"][2] == 0
+    for name in ("peer", "loop"):
+        np.testing.assert_array_equal(res[name][0][0], res["rccl"][0][0])
+        np.testing.assert_array_equal(res[name][0][1], res["rccl"][0][1])
+
+
 def test_loops_capacity_is_reported_before_any_worst_case_allocation(pkg):
     fs = pkg.synth.make_frames(80, 600, seed=77, dup_frac=0.2)
     p = pkg.default_params()
@@ -246,11 +265,17 @@ def test_real_multi_device_group(pkg, oracle):
     p = pkg.default_params()
     p.min_gap = 3
     p.min_matches = 20
-    for world in sorted({2, min(n_dev, 4), min(n_dev, 8)}):
-        with pkg.Group(p, n_devices=world) as g, pkg.Matcher(p) as m:
+    for world, peer in [(w, t) for w in sorted({2, min(n_dev, 4), min(n_dev, 8)}) for t in (False, True)]:
+        with pkg.Group(p, n_devices=world, peer_copies=peer) as g, pkg.Matcher(p) as m:
             fill(fs, g, m)
             check_group_against_single(pkg, oracle, g, m, fs, 3, world)
-            assert g.info().rccl_ranks == world and g.info().loopback == 0 and g.info().gathered_score_bytes > 0
+            assert g.info().loopback == 0 and g.info().gathered_score_bytes > 0
+            if peer:
+                assert g.transport.startswith("peer copies") and g.info().rccl_ranks == 0
+            elif g.transport == "rccl":
+                assert g.info().rccl_ranks == world
+            else:
+                print("NOTE: RCCL communicator not available on this box, the group fell back to:", g.transport)
             q = fs.frame(20)
             np.testing.assert_array_equal(g.query_scores(q, 9000)[0], m.query_scores(q, 9000)[0])
             qb, qids = [fs.frame(5), fs.frame(7), fs.frame(40)], [9000, 9001, 60]
