@@ -27,10 +27,16 @@ def _sample_pairs(rng, n_frames, n, owned_mod=None):
     return np.array(qs), np.array(ts)
 
 
-def test_cfg4_fullsize_fused_filter_and_loop_test(pkg, oracle):
+@pytest.mark.parametrize("selective", [False, True])
+def test_cfg4_fullsize_fused_filter_and_loop_test(pkg, oracle, selective):
     """configs[3]: 5000 frames x 2000 descriptors, 12,352,935 pairs scored, filtered (2 x min distance) and
-    loop-tested (>= 50 matches, similarity > 0.15) entirely on the device by lcm_all_vs_all_loops."""
-    fs = pkg.synth.make_frames(5000, 2000, seed=pkg.synth.BASE_SEED + 4)
+    loop-tested (>= 50 matches, similarity > 0.15) entirely on the device by lcm_all_vs_all_loops — on the default
+    synthetic variant (nearly every pair passes: the filter is vacuous for unrelated frames) and on the SELECTIVE one
+    (30 shared pool descriptors per frame: unrelated pairs keep ~30 matches and fail, candidates are revisits only);
+    the selective run is repeated through a 4-shard loopback group (lcm_group_all_vs_all_loops: the loop test on every
+    shard's device, only candidates leaving it) and must return the same candidates."""
+    make = pkg.synth.make_frames_selective if selective else pkg.synth.make_frames
+    fs = make(5000, 2000, seed=pkg.synth.BASE_SEED + 4)
     p = pkg.default_params()
     p.min_gap = GAP
     with pkg.Matcher(p) as m:
@@ -42,9 +48,9 @@ def test_cfg4_fullsize_fused_filter_and_loop_test(pkg, oracle):
             m.append_device(int(fs.ids[f]), d_rows + f * fb, int(fs.counts[f]))
         # nearly every pair is a "loop" by the README's rule on this data (unrelated frames: best distances 88..107,
         # so 2 x min keeps all 2000 matches): the candidate buffer must hold one record per pair
-        cands, n_pairs = m.all_vs_all_loops(out=np.zeros(12352935, pkg.capi.CANDIDATE_DTYPE))
+        cands, n_pairs = m.all_vs_all_loops(out=np.zeros(1 << 16 if selective else 12352935, pkg.capi.CANDIDATE_DTYPE))
         info = m.launch_info()
-        print(f"cfg4 fused: score kernel {info.kernel_ms:.0f} ms = {info.distances / info.kernel_ms / 1e9:.3f}e12 distances/s, loop-test kernels {info.aux_kernel_ms:.3f} ms")
+        print(f"cfg4 fused ({'selective' if selective else 'default'} variant): {len(cands)} candidates; score kernel {info.kernel_ms:.0f} ms = {info.distances / info.kernel_ms / 1e9:.3f}e12 distances/s, loop-test kernels {info.aux_kernel_ms:.3f} ms")
         assert n_pairs == 12352935 == pkg.synth.n_pairs_all_vs_all(5000, GAP)
         assert info.distances == n_pairs * 2000 * 2000 and info.aux_kernel_ms > 0
         scores = m.last_bulk_scores()
@@ -62,6 +68,14 @@ def test_cfg4_fullsize_fused_filter_and_loop_test(pkg, oracle):
     keep = np.nonzero((sim > 0.15) & (good >= 50))[0]
     assert len(keep) > 500 and (~((sim > 0.15) & (good >= 50))).sum() > 500     # both verdicts occur
     assert len(cands) == len(keep)
+    if selective:
+        n_places = fs.n_frames // 4
+        assert len(keep) < n_pairs // 1000                                       # sparse: ~0.02 % of the pairs ...
+        assert ((c_of[keep] % n_places) == (t_of[keep] % n_places)).all()         # ... every one a revisit of a place
+        unrelated = (c_of % n_places) != (t_of % n_places)
+        assert good[unrelated].max() < 50 and 20 <= np.median(good[unrelated]) <= 40      # the pool matches, and only those
+    else:
+        assert len(keep) > n_pairs * 0.99
     np.testing.assert_array_equal(cands["current_frame_id"], fs.ids[c_of[keep]])
     np.testing.assert_array_equal(cands["matched_frame_id"], fs.ids[t_of[keep]])
     np.testing.assert_array_equal(cands["num_matches"], good[keep])
@@ -84,6 +98,15 @@ def test_cfg4_fullsize_fused_filter_and_loop_test(pkg, oracle):
     cpu, _, _ = oracle.fast_score_pairs(fs.rows, fs.counts, qs, ts, oracle.default_params(min_gap=GAP), n_threads=8)
     np.testing.assert_array_equal(scores[offs[qs] + ts], cpu)
     assert (scores["n_train"] == 2000).all()
+
+    if selective:
+        with pkg.Group(p, n_devices=4, loopback_device=0) as g:
+            g.reserve(fs.n_frames, fs.stride_rows)
+            for f in range(fs.n_frames):
+                g.append(int(fs.ids[f]), fs.frame(f))
+            gc, gp = g.all_vs_all_loops(cap=1 << 16)
+            assert gp == n_pairs
+            np.testing.assert_array_equal(gc, cands)
 
 
 def test_cfg3_rank_slice_of_the_sharded_search(pkg, oracle):
