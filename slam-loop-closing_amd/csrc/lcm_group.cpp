@@ -205,6 +205,7 @@ int run_all(lcm_group* g, F&& fn) {
         try { rc = fn(r); }
         catch (const std::bad_alloc&) { rc = fail(LCM_ERR_OOM, "host allocation failed (std::bad_alloc)"); }
         catch (const std::exception& e) { rc = fail(LCM_ERR_HIP, "unexpected C++ exception: %s", e.what()); }
+        catch (...) { rc = fail(LCM_ERR_HIP, "unexpected C++ exception"); }
         rcs[(size_t)r] = rc;
         if (rc) errs[(size_t)r] = lcm::last_error();
     };
