@@ -406,9 +406,13 @@ LCM_API int  lcm_merge_shard_scores_device(lcm_handle* h, const void* d_gathered
  *                         fails — the next plan starts from the configured size again).  Device footprint of a handle
  *                         beyond its database: this scratch (allocated at the first packed search, given back when a
  *                         later search needs less than a quarter of it), 8 bytes per pair of the fused loop search's
- *                         score array, and the staging of up to 4 online queries. */
+ *                         score array, and the staging of up to 4 online queries.
+ *   LCM_TUNE_PAIR_UPLOAD_KERNEL  pair mode, calls of <= 64 M distances: the staging block is uploaded by a kernel on the
+ *                         compute queue (1, default) or by hipMemcpyAsync (0)
+ *   LCM_TUNE_PAIR_HOST_FOLD      ... and the fold kernel writes the folded keys straight into pinned host memory (1,
+ *                         default) or into device memory followed by a copy (0) */
 typedef enum lcm_tuning { LCM_TUNE_ITEM_SLOTS = 0, LCM_TUNE_ONLINE_SPLIT = 1, LCM_TUNE_PACKED = 2, LCM_TUNE_ONLINE_STREAMS = 3,
-                          LCM_TUNE_PACKED_SCRATCH_MB = 4 } lcm_tuning;
+                          LCM_TUNE_PACKED_SCRATCH_MB = 4, LCM_TUNE_PAIR_UPLOAD_KERNEL = 5, LCM_TUNE_PAIR_HOST_FOLD = 6 } lcm_tuning;
 LCM_API int  lcm_set_tuning(lcm_handle* h, int knob, int value);
 
 /* Device scratch helpers so a host program needs no other allocator (plain hipMalloc/hipFree/hipMemcpy). */

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("LCM_LIB_PATH") or os.path.join(_HERE, "lib", "liblcm_
 DESC_BYTES = 32
 KEY_SHIFT = 22
 TUNE_ITEM_SLOTS, TUNE_ONLINE_SPLIT, TUNE_PACKED, TUNE_ONLINE_STREAMS, TUNE_PACKED_SCRATCH_MB = 0, 1, 2, 3, 4      # lcm_tuning
+TUNE_PAIR_UPLOAD_KERNEL, TUNE_PAIR_HOST_FOLD = 5, 6
 
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_ORDER, ERR_NOT_FOUND, ERR_OOM = 0, -1, -2, -3, -4, -5, -6, -7   # lcm_status

@@ -295,6 +295,12 @@ int lcm_set_tuning(lcm_handle* h, int knob, int value) {
         case LCM_TUNE_ONLINE_STREAMS:
             if (value != 0 && value != 1) return fail(LCM_ERR_INVALID_ARG, "online streams must be 0 (the handle's stream) or 1 (one per query slot)");
             h->tune_online_streams = value; return LCM_OK;
+        case LCM_TUNE_PAIR_UPLOAD_KERNEL:
+            if (value != 0 && value != 1) return fail(LCM_ERR_INVALID_ARG, "pair upload must be 0 (hipMemcpyAsync) or 1 (kernel)");
+            h->tune_pair_upload_kernel = value; return LCM_OK;
+        case LCM_TUNE_PAIR_HOST_FOLD:
+            if (value != 0 && value != 1) return fail(LCM_ERR_INVALID_ARG, "pair host fold must be 0 (device buffer + copy) or 1 (pinned host memory)");
+            h->tune_pair_host_fold = value; return LCM_OK;
         case LCM_TUNE_PACKED_SCRATCH_MB:
             if (value < 1 || value > 65536) return fail(LCM_ERR_INVALID_ARG, "packed scratch must be 1 .. 65536 MiB per chunk");
             h->pk_scratch_cfg_words = h->pk_scratch_words = (size_t)value << 18; h->plan.key = 0; return LCM_OK;

@@ -165,6 +165,8 @@ struct lcm_handle {
     int variant = 0;
     int tune_item_slots = 0;           // 0 = automatic (pick_chunk)
     int tune_online_split = -1;        // -1 = automatic (enqueue_query)
+    int tune_pair_upload_kernel = 1;   // pair mode, latency shape: staging block uploaded by a kernel (1) or by hipMemcpyAsync (0)
+    int tune_pair_host_fold = 1;       // ... and the fold kernel writes into pinned host memory (1) or into device memory + a copy (0)
     int tune_online_streams = 1;       // 1 = every query slot runs on its own stream, 0 = all on the handle's stream
     // packed route: 4-byte words of per-row scratch per chunk.  _cfg is what LCM_TUNE_PACKED_SCRATCH_MB asked for (default
     // 1 GiB); the effective size is halved when the allocation fails and goes back to _cfg at the next plan rebuild.

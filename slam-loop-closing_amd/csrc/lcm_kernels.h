@@ -125,6 +125,9 @@ struct FoldArgs {
     uint32_t        n_pairs;
 };
 hipError_t launch_fold_pair_keys(const FoldArgs& a, uint32_t max_nq, hipStream_t st);
+// bytes (rounded up to 16; both buffers must have that room, 16-byte aligned) from PINNED host memory to device memory, by
+// a kernel on `st` instead of a DMA-engine copy (latency-critical small uploads)
+hipError_t launch_upload(void* d_dst, const void* h_src_pinned, size_t bytes, hipStream_t st);
 // Pair mode, first step, LATENCY shape: items of <= 512 query rows on 256-thread workgroups of 2 rows per lane.  One
 // matchFeatures call is a few hundred thousand distances per wave whatever the shape, and a wave alone on its SIMD issues
 // one VALU instruction per ~8 cycles: what shortens the call is MORE waves with less work each, not fewer instructions

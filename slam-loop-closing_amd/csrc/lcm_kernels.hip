@@ -642,21 +642,48 @@ __global__ __launch_bounds__(256) void k_finalize_pairs(FinalizeArgs a, uint32_t
     }
 }
 
+// 32 query rows per workgroup, 8 threads per row: thread (row, part) folds segments part, part + 8, ... (a handful of
+// independent loads instead of one thread walking all segments one dependent load after the other — that walk was most
+// of a single matchFeatures call's fold time), the 8 partial minima meet in LDS.
 __global__ __launch_bounds__(256) void k_fold_pair_keys(FoldArgs a) {
+    __shared__ uint32_t part_min[8][32];
     const PairDesc p = a.pairs[blockIdx.y];
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= p.nq) return;
+    const uint32_t rr = threadIdx.x & 31u, part = threadIdx.x >> 5;
+    const uint32_t r = blockIdx.x * 32u + rr;
     const uint32_t CR = a.chunk_rows ? a.chunk_rows : (uint32_t)MAX_FUSED_QUERY_ROWS;
-    const uint32_t c = r / CR, lr = r % CR;
-    const uint32_t* src = a.seg_keys + ((size_t)p.first_item + (size_t)c * p.n_seg) * CR + lr;
     uint32_t best = 0xFFFFFFFFu;
-    for (uint32_t g = 0; g < p.n_seg; ++g) best = min(best, src[(size_t)g * CR] + g * p.seg_rows);
-    a.final_keys[p.out_row0 + r] = best;
+    if (r < p.nq) {
+        const uint32_t c = r / CR, lr = r % CR;
+        const uint32_t* src = a.seg_keys + ((size_t)p.first_item + (size_t)c * p.n_seg) * CR + lr;
+        for (uint32_t g = part; g < p.n_seg; g += 8) best = min(best, src[(size_t)g * CR] + g * p.seg_rows);
+    }
+    part_min[part][rr] = best;
+    __syncthreads();
+    if (part == 0 && r < p.nq) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) best = min(best, part_min[k][rr]);
+        a.final_keys[p.out_row0 + r] = best;
+    }
 }
 
 hipError_t launch_fold_pair_keys(const FoldArgs& a, uint32_t max_nq, hipStream_t st) {
     if (a.n_pairs == 0 || max_nq == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fold_pair_keys, dim3((max_nq + 255) / 256, a.n_pairs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_fold_pair_keys, dim3((max_nq + 31) / 32, a.n_pairs), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// Upload by kernel: n16 16-byte words from pinned host memory (mapped into the device's address space) to device memory.
+// For the pair mode's staging block (<= a few hundred KB): on the compute queue a copy is followed by the kernel that
+// needs it after a normal kernel-to-kernel gap, where a DMA-engine copy costs a cross-engine hand-over first.
+__global__ __launch_bounds__(256) void k_upload_u4(uint4* __restrict__ dst, const uint4* __restrict__ src, uint32_t n16) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+hipError_t launch_upload(void* d_dst, const void* h_src_pinned, size_t bytes, hipStream_t st) {
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    if (n16 == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_upload_u4, dim3((n16 + 255) / 256), dim3(256), 0, st, (uint4*)d_dst, (const uint4*)h_src_pinned, n16);
     return hipGetLastError();
 }
 

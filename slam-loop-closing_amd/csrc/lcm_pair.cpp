@@ -87,7 +87,15 @@ static int run_pair_jobs(lcm_handle* h, const uint8_t* d_q_base, const uint8_t* 
     rc = ensure_pinned(h->h_final_keys, h->h_final_keys_n, total_rows); if (rc) return rc;
     // only the part the caller did not fill needs the copy when the rows are device-resident already
     const size_t up_from = (q_in_stage || t_in_stage) ? 0 : off_items;
-    HIP_TRY(hipMemcpyAsync(h->d_pair_stage + up_from, h->h_pair_stage + up_from, up_bytes - up_from, hipMemcpyHostToDevice, h->stream));
+    if (small && h->tune_pair_upload_kernel) {
+        // latency shape: the staging block goes up by a KERNEL on the compute queue (the score kernel follows it after a
+        // normal kernel-to-kernel gap; a DMA copy hands over across engines first: ~6 us more per call)
+        const size_t from16 = up_from & ~(size_t)15;
+        const hipError_t eu = lcm::launch_upload(h->d_pair_stage + from16, h->h_pair_stage + from16, up_bytes - from16, h->stream);
+        if (eu != hipSuccess) return fail(LCM_ERR_HIP, "upload kernel launch failed: %s", hipGetErrorString(eu));
+    } else {
+        HIP_TRY(hipMemcpyAsync(h->d_pair_stage + up_from, h->h_pair_stage + up_from, up_bytes - up_from, hipMemcpyHostToDevice, h->stream));
+    }
 
     lcm::ScoreArgs a{};
     a.q_rows = (const uint32_t*)(q_in_stage ? h->d_pair_stage : d_q_base);
@@ -112,7 +120,8 @@ static int run_pair_jobs(lcm_handle* h, const uint8_t* d_q_base, const uint8_t* 
     // Latency shape: the fold kernel writes the folded keys STRAIGHT into the pinned host buffer (mapped into the device's
     // address space; 4 bytes per query row over PCIe), so no device-to-host copy packet follows it: the stream's
     // synchronisation below is also the hand-over.  Throughput shape: device buffer + one copy.
-    f.final_keys = small ? h->h_final_keys : h->d_keys + n_items * (size_t)CH;
+    const bool host_fold = small && h->tune_pair_host_fold;
+    f.final_keys = host_fold ? h->h_final_keys : h->d_keys + n_items * (size_t)CH;
     f.n_pairs = (uint32_t)P;
     hipError_t e = lcm::launch_fold_pair_keys(f, (uint32_t)max_nq, h->stream);
     if (e != hipSuccess) return fail(LCM_ERR_HIP, "fold kernel launch failed: %s", hipGetErrorString(e));
@@ -122,7 +131,7 @@ static int run_pair_jobs(lcm_handle* h, const uint8_t* d_q_base, const uint8_t* 
         h->info.distances += (uint64_t)jb.nq * (uint64_t)jb.nt;
         h->info.algo_bytes += (uint64_t)jb.nt * 32 + (uint64_t)jb.nq * 32 + 8;
     }
-    if (!small) HIP_TRY(hipMemcpyAsync(h->h_final_keys, f.final_keys, sizeof(uint32_t) * total_rows, hipMemcpyDeviceToHost, h->stream));
+    if (!host_fold) HIP_TRY(hipMemcpyAsync(h->h_final_keys, f.final_keys, sizeof(uint32_t) * total_rows, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     *keys_out = h->h_final_keys;
     return LCM_OK;

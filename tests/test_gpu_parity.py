@@ -113,3 +113,23 @@ def test_filter_params_take_effect(matcher, oracle, pkg):
             np.testing.assert_array_equal(m["train_idx"], om["train_idx"])
     finally:
         matcher.set_params(ratio=old.ratio, dist_floor=old.dist_floor)
+
+
+@pytest.mark.parametrize("upload_kernel,host_fold", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_pair_mode_latency_paths_give_the_same_matches(pkg, oracle, upload_kernel, host_fold):
+    """The latency shape of the pair mode (calls of <= 64 M distances) has two switches — staging block uploaded by a
+    kernel or by hipMemcpyAsync, folded keys written into pinned host memory or into device memory + a copy: all four
+    combinations, ragged sizes on both sides of the 512-row chunk and the segment seams, against the oracle; and a call
+    above the 64 M-distance limit (throughput shape) between them."""
+    rng = np.random.default_rng(77)
+    with pkg.Matcher() as m:
+        m.set_tuning(pkg.capi.TUNE_PAIR_UPLOAD_KERNEL, upload_kernel)
+        m.set_tuning(pkg.capi.TUNE_PAIR_HOST_FOLD, host_fold)
+        for nq, nt in [(2000, 2000), (1, 1), (513, 31), (512, 33), (1025, 4097), (37, 20000), (3000, 700), (9000, 8000), (300, 300)]:
+            q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+            t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+            t[rng.integers(0, nt, max(nt // 7, 1))] = q[rng.integers(0, nq, max(nt // 7, 1))]      # exact copies: ties on distance 0
+            idx, dist = m.match_pair(q, t)
+            oi, od = oracle.bf_match(q, t)
+            np.testing.assert_array_equal(idx, oi, err_msg=f"{nq} x {nt}")
+            np.testing.assert_array_equal(dist.astype(np.int32), od, err_msg=f"{nq} x {nt}")

@@ -123,6 +123,8 @@ def test_random_api_sequences_equal_oracle(pkg, oracle, tmp_path, seed):
                 m.set_tuning(pkg.capi.TUNE_ONLINE_SPLIT, int(rng.choice([-1, 0, 1, 2, 4, 16, 32])))
                 m.set_tuning(pkg.capi.TUNE_ONLINE_STREAMS, int(rng.choice([0, 1])))
                 m.set_tuning(pkg.capi.TUNE_PACKED_SCRATCH_MB, int(rng.choice([1, 2, 1024])))     # 1 MiB: 64 pairs per chunk -> 2-D chunks
+                m.set_tuning(pkg.capi.TUNE_PAIR_UPLOAD_KERNEL, int(rng.choice([0, 1])))
+                m.set_tuning(pkg.capi.TUNE_PAIR_HOST_FOLD, int(rng.choice([0, 1])))
             elif op in ("bulk", "loops") and model.frames:
                 rows, counts = model.arrays()
                 pq, pt, offs = [], [], [0]

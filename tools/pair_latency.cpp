@@ -12,6 +12,10 @@ int main() {
     lcm_handle* h = nullptr;
     if (lcm_create(nullptr, 0, nullptr, &h) != LCM_OK) { printf("lcm_create: %s\n", lcm_last_error()); return 1; }
     std::mt19937 rng(1);
+    for (int mode = 0; mode < 4; ++mode) {
+    lcm_set_tuning(h, LCM_TUNE_PAIR_UPLOAD_KERNEL, mode & 1);
+    lcm_set_tuning(h, LCM_TUNE_PAIR_HOST_FOLD, (mode >> 1) & 1);
+    printf("upload by %s, fold into %s\n", (mode & 1) ? "kernel" : "hipMemcpyAsync", (mode & 2) ? "pinned host memory" : "device memory + copy");
     const int shapes[][2] = {{2000, 2000}, {500, 500}, {2000, 20000}};
     for (auto& sh : shapes) {
         const int nq = sh[0], nt = sh[1];
@@ -38,6 +42,7 @@ int main() {
         lcm_last_launch_info(h, &li);
         printf("%5d x %5d: lcm_match_pair median %.1f us (p10 %.1f), lcm_match_features median %.1f us; score kernel %.1f us on %u workgroups\n",
                nq, nt, a[a.size() / 2], a[a.size() / 10], b[b.size() / 2], li.kernel_ms * 1e3, li.workgroups);
+    }
     }
     lcm_destroy(h);
     return 0;
