@@ -445,6 +445,25 @@ def cfg3_whole_extra(entry, pkg, torch, dev, local_rank, gap):
     return out
 
 
+def pair_mode_extra(pkg, fs):
+    """matchFeatures as one call (LoopClosingSystem::matchFeatures, include/loop_closing.hpp:40): wall clock of lcm_match_features
+    for two 2000-row frames of the workload, host rows in pageable memory, through this process's ctypes binding (a C++
+    caller saves ~7 us: tools/pair_latency.cpp)."""
+    q, t = np.ascontiguousarray(fs.frame(fs.n_frames - 1)), np.ascontiguousarray(fs.frame(3))
+    with pkg.Matcher() as m:
+        for _ in range(5):
+            m.match_features(q, t)
+        ts = []
+        for _ in range(100):
+            t0 = time.perf_counter()
+            good, md = m.match_features(q, t)
+            ts.append(time.perf_counter() - t0)
+        li = m.launch_info()
+    return {"api": "lcm_match_features", "rows": [int(len(q)), int(len(t))], "median_us": float(np.median(ts) * 1e6),
+            "p10_us": float(np.percentile(ts, 10) * 1e6), "score_kernel_us": li.kernel_ms * 1e3, "workgroups": int(li.workgroups),
+            "good_matches": int(len(good)), "min_dist": int(md)}
+
+
 def group_rehearsal_extra(pkg, fs, gap, expect, expect_idx, world, loopback):
     """cfg2 through lcm_group_all_vs_all_argmin: a group of ONE device (ncclCommInitAll, all-gather of the shard arena, search,
     gather, device merge, one download) or W shards on this ONE GPU (lcm_group_create_loopback: exchange steps as device-
@@ -1021,7 +1040,8 @@ def main():
             m.close()
             del scores, d_rows, idx_sums
             torch.cuda.empty_cache()
-            out["extra"] = {"group_of_one": group_rehearsal_extra(pkg, fs, args.gap, single, single_idx, 1, False),
+            out["extra"] = {"pair_mode": pair_mode_extra(pkg, fs),
+                            "group_of_one": group_rehearsal_extra(pkg, fs, args.gap, single, single_idx, 1, False),
                             "group_loopback_8": group_rehearsal_extra(pkg, fs, args.gap, single, single_idx, 8, True),
                             "cfg4_fused": cfg4_fused_extra(pkg, torch, dev, local_rank, args.gap, False),
                             "cfg4_fused_selective": cfg4_fused_extra(pkg, torch, dev, local_rank, args.gap, True),

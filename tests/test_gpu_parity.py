@@ -125,7 +125,10 @@ def test_pair_mode_latency_paths_give_the_same_matches(pkg, oracle, upload_kerne
     with pkg.Matcher() as m:
         m.set_tuning(pkg.capi.TUNE_PAIR_UPLOAD_KERNEL, upload_kernel)
         m.set_tuning(pkg.capi.TUNE_PAIR_HOST_FOLD, host_fold)
-        for nq, nt in [(2000, 2000), (1, 1), (513, 31), (512, 33), (1025, 4097), (37, 20000), (3000, 700), (9000, 8000), (300, 300)]:
+        shapes = [(2000, 2000), (1, 1), (513, 31), (512, 33), (1025, 4097), (37, 20000), (3000, 700), (300, 300)]
+        if upload_kernel and host_fold:
+            shapes.insert(5, (9000, 8000))           # 72 M distances: the throughput shape, between two latency-shaped calls
+        for nq, nt in shapes:
             q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
             t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
             t[rng.integers(0, nt, max(nt // 7, 1))] = q[rng.integers(0, nq, max(nt // 7, 1))]      # exact copies: ties on distance 0
