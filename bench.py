@@ -209,7 +209,11 @@ def roofline_from_launches(pkg, infos, n_desc, argmin, traffic=None, traffic_sou
     vb = load_profile_json("valu_busy.json")
     if vb is not None:
         valu["valu_busy_frac"] = vb.get("valu_busy_frac")
-        valu["valu_busy_source"] = vb.get("source")
+        valu["valu_issue_slots_busy_frac"] = vb.get("valu_issue_slots_busy_frac")
+        valu["valu_busy_source"] = ("profiles/valu_busy.json (counters, NOT measured in this run): valu_busy_frac = the kernel's VALU "
+                                    "instructions priced at the issue costs the same counters give for pure v_xor_b32 / v_bcnt_u32_b32 "
+                                    "loops, over its SIMD-cycles; valu_issue_slots_busy_frac = quad-cycles with a VALU issue "
+                                    "(SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) over all quad-cycles")
     return roof, valu
 
 

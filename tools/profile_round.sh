@@ -32,6 +32,12 @@ echo "valu rc=$?"
 rocprofv3 --kernel-trace --pmc $VC -d "$OUT/valu_ref" -o p --output-format csv -- $PWD/tools/valu_busy 0.05 > "$OUT/valu_ref.txt" 2> "$OUT/valu_ref.log"
 echo "valu_ref rc=$?"
 $PWD/tools/valu_busy 0.05 > "$OUT/valu_ref_unprofiled.txt" 2>&1
+# ... and the gfx950 dual-issue counter: quad-cycles in which two VALU instructions were issued
+V2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
+rocprofv3 --kernel-trace --pmc $V2 -d "$OUT/valu2" -o p --output-format csv -- $B $ONE > /dev/null 2> "$OUT/valu2.log"
+echo "valu2 rc=$?"
+rocprofv3 --kernel-trace --pmc $V2 -d "$OUT/valu2_ref" -o p --output-format csv -- $PWD/tools/valu_busy 0.05 > "$OUT/valu2_ref.txt" 2> "$OUT/valu2_ref.log"
+echo "valu2_ref rc=$?"
 if [ -z "$QUICK" ]; then
 # 5. the online path: micro-batched streaming over 1000 frames, kernel statistics + bench's own busy fraction
 rocprofv3 --kernel-trace --stats -d "$OUT/stream" -o st --output-format csv -- $B --mode stream --frames 1000 --steps 1 --warmup 1 --cpu-seconds 0 > "$OUT/stream_bench.json" 2> "$OUT/stream.log"

@@ -86,7 +86,33 @@ head = [k for k in out["kernels"] if "8, 1, false, true" in k]
 if head:
     out["valu_busy_frac"] = out["kernels"][head[0]]["valu_busy_frac"]
     out["kernel"] = head[0]
+# ---- optional third pair of passes (valu2 / valu2_ref): SQ_ACTIVE_INST_VALU2, a gfx950 counter: quad-cycles in which TWO
+# VALU instructions were issued on a SIMD.  A quad-cycle holds either one 4-cycle-class instruction or up to two 2-cycle-
+# class ones, so  quads with a VALU issue = SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2, and that over all quad-cycles of
+# the kernel (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs / 4) is the fraction of issue slots in use: a DIRECT busy measure.
+if os.path.exists(os.path.join(prof, "valu2", "p_counter_collection.csv")):
+    dual = {}
+    for sub in ("valu2_ref", "valu2"):
+        agg, _ = load(sub)
+        for name, c in agg.items():
+            if "k_score_rowlane" not in name and "k_p" not in name:
+                continue
+            quads = c["GRBM_GUI_ACTIVE"] / 8.0 * N_SIMD / 4.0
+            inst, two = c["SQ_ACTIVE_INST_VALU"], c.get("SQ_ACTIVE_INST_VALU2", 0.0)
+            dual[name] = {"valu_instructions_per_quad_cycle": inst / quads, "quad_cycles_with_two_valu_issued_frac": two / quads,
+                          "quad_cycles_with_a_valu_issue_frac": (inst - two) / quads,
+                          "raw": {k: c[k] for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "GRBM_GUI_ACTIVE")}}
+    out["dual_issue"] = {"counter": "SQ_ACTIVE_INST_VALU2 (gfx950: quad-cycles in which two VALU instructions are issued, per SIMD)",
+                         "kernels": dual}
+    for name, d in dual.items():
+        if "8, 1, false, true" in name:
+            out["valu_issue_slots_busy_frac"] = d["quad_cycles_with_a_valu_issue_frac"]
 json.dump(out, open(out_path, "w"), indent=1)
+if "dual_issue" in out:
+    print("SQ_ACTIVE_INST_VALU2 (quad-cycles with two VALU instructions issued):")
+    for name, d in out["dual_issue"]["kernels"].items():
+        print("  %-62s %.3f instr per quad, dual quads %.3f, quads with a VALU issue %.3f" % (
+            name[:62], d["valu_instructions_per_quad_cycle"], d["quad_cycles_with_two_valu_issued_frac"], d["quad_cycles_with_a_valu_issue_frac"]))
 print("issue cost, SIMD-cycles per wave64 instruction: v_xor_b32 %.3f   v_bcnt_u32_b32 %.3f   ratio %.2f" % (cost_xor, cost_bcnt, cost_bcnt / cost_xor))
 for key, d in refs.items():
     print("  %-12s %.3f cycles per VALU instruction, %.1f active lanes, waiting to issue %.0f %% of wave-cycles%s" % (
