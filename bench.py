@@ -233,8 +233,10 @@ def lookup_traffic(wl, world, n_frames, variant, packed):
         return None, None
     if (t.get("workload") == wl and t.get("n_gpus") == world and t.get("frames") == n_frames
             and t.get("kernel_variant", 0) == variant and bool(t.get("packed", False)) == packed):
-        return t.get("hbm_bytes_per_launch"), ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same "
-                                               "command, per score launch like `achieved`, NOT measured in this run")
+        return t.get("hbm_bytes_per_launch"), ("profiles/hbm_traffic.json: rocprofv3 --pmc passes of this same command, per score launch like "
+                                               "`achieved`, NOT measured in this run; reads = 32 x TCC_EA0_RDREQ_32B + 64 x _64B + 128 x _128B "
+                                               "(exact, calibrated on known byte counts: FETCH_SIZE prices a 128-byte request at 64 bytes), "
+                                               "writes = WRITE_SIZE")
     return None, None
 
 

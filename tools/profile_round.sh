@@ -21,6 +21,17 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o p --output-format c
 echo "fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o p --output-format csv -- $B $ONE > /dev/null 2> "$OUT/write.log"
 echo "write rc=$?"
+# 2b. EXACT read bytes: the size-resolved request counters (FETCH_SIZE tallies a 128-byte request as 64 bytes), and where the
+#     requests go; the same passes over tools/fetch_calib (2^30 bytes read once per access pattern) calibrate both
+R1="TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum"
+R2="TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RDREQ_GMI_32B_sum TCC_EA0_RDREQ_IO_32B_sum"
+rocprofv3 --kernel-trace --pmc $R1 -d "$OUT/rd" -o p --output-format csv -- $B $ONE > /dev/null 2> "$OUT/rd.log"
+echo "rd rc=$?"
+rocprofv3 --kernel-trace --pmc $R2 -d "$OUT/rd2" -o p --output-format csv -- $B $ONE > /dev/null 2> "$OUT/rd2.log"
+echo "rd2 rc=$?"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch_calib" -o p --output-format csv -- $PWD/tools/fetch_calib > /dev/null 2> "$OUT/fetch_calib.log"
+rocprofv3 --kernel-trace --pmc $R1 -d "$OUT/rd_calib" -o p --output-format csv -- $PWD/tools/fetch_calib > /dev/null 2> "$OUT/rd_calib.log"
+echo "calib rc=$?"
 # 3. instruction mix (SQ block: 8 slots)
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/sq" -o p --output-format csv -- $B $ONE > /dev/null 2> "$OUT/sq.log"
 echo "sq rc=$?"
