@@ -338,6 +338,11 @@ LCM_API int  lcm_group_append(lcm_group* g, int frame_id, const uint8_t* desc, i
 LCM_API int  lcm_group_clear(lcm_group* g);
 /* Keep the first n_frames frames (arrival order), drop the rest; tickets in flight become void (lcm_db_truncate per shard). */
 LCM_API int  lcm_group_truncate(lcm_group* g, int n_frames);
+/* Snapshot / resume in lcm_db_save's own file format, frames in arrival order: a file written by a group of 8 loads
+ * into a single handle or a group of any size, and the other way round.  Load replaces the group's contents (same
+ * validation as lcm_db_load: header checked against the file before anything is touched; empty group on a later error). */
+LCM_API int  lcm_group_save(lcm_group* g, const char* path);
+LCM_API int  lcm_group_load(lcm_group* g, const char* path);
 LCM_API int  lcm_group_sync(lcm_group* g);                                   /* lcm_sync on every shard */
 LCM_API int  lcm_group_set_tuning(lcm_group* g, int knob, int value);        /* lcm_set_tuning on every shard */
 LCM_API int  lcm_group_set_kernel_variant(lcm_group* g, int variant);        /* lcm_set_kernel_variant on every shard */

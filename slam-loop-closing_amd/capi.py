@@ -143,6 +143,8 @@ _SIGNATURES = {
     "lcm_group_append": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
     "lcm_group_clear": (C.c_int, [_vp]),
     "lcm_group_truncate": (C.c_int, [_vp, C.c_int]),
+    "lcm_group_save": (C.c_int, [_vp, C.c_char_p]),
+    "lcm_group_load": (C.c_int, [_vp, C.c_char_p]),
     "lcm_group_sync": (C.c_int, [_vp]),
     "lcm_group_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "lcm_group_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
@@ -616,6 +618,12 @@ class Group:
 
     def truncate(self, n_frames: int):
         _check(self._lib.lcm_group_truncate(self._g, n_frames))
+
+    def save(self, path: str):
+        _check(self._lib.lcm_group_save(self._g, path.encode()))
+
+    def load(self, path: str):
+        _check(self._lib.lcm_group_load(self._g, path.encode()))
 
     def sync(self):
         _check(self._lib.lcm_group_sync(self._g))

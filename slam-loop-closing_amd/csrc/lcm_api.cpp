@@ -414,10 +414,7 @@ static int db_save_impl(lcm_handle* h, const char* path) {
     int rc = lcm_sync(h); if (rc) return rc;
     FILE* f = fopen(path, "wb");
     if (!f) return fail(LCM_ERR_INVALID_ARG, "cannot open %s for writing", path);
-    SnapHeader hd{{'L', 'C', 'M', 'D', 'B', '0', '1', 0}, 1u, (uint32_t)h->frames.size(), 0u, 0u};
-    for (const FrameMeta& m : h->frames) hd.max_rows = std::max<uint32_t>(hd.max_rows, (uint32_t)m.n);
-    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1;
-    if (!h->frames.empty()) ok = ok && fwrite(h->frames.data(), sizeof(FrameMeta), h->frames.size(), f) == h->frames.size();
+    bool ok = lcm::snapshot_write_header(f, h->frames);
     std::vector<uint8_t> buf;
     for (size_t s = 0; ok && s < h->frames.size(); ++s) {
         const size_t bytes = (size_t)h->frames[s].n * LCM_DESC_BYTES;
@@ -430,14 +427,16 @@ static int db_save_impl(lcm_handle* h, const char* path) {
     return ok ? LCM_OK : fail(LCM_ERR_HIP, "writing %s failed", path);
 }
 
-static int db_load_impl(lcm_handle* h, const char* path) {
-    if (!h || !path) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+extern "C++" {
+namespace lcm {
+// Opens and VALIDATES a database snapshot: everything the header claims is checked against the file's real size BEFORE
+// anything is allocated or any database is touched — a corrupt or hostile header can neither trigger a huge allocation
+// nor cost the caller the frames it already has.  On LCM_OK *f_out is positioned at the first frame's rows (caller closes).
+int snapshot_open(const char* path, std::vector<FrameMeta>& metas, uint32_t* real_max_rows, FILE** f_out) {
+    *f_out = nullptr;
     FILE* f = fopen(path, "rb");
     if (!f) return fail(LCM_ERR_NOT_FOUND, "cannot open %s", path);
-    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
-    // Everything the header claims is checked against the file's real size BEFORE anything is allocated or the
-    // current database is touched: a corrupt or hostile header can neither trigger a huge allocation nor cost the
-    // caller the frames it already has.
+    struct Closer { FILE* f; bool keep = false; ~Closer() { if (!keep) fclose(f); } } closer{f};
     struct stat st{};
     if (fstat(fileno(f), &st) != 0 || st.st_size < 0) return fail(LCM_ERR_INVALID_ARG, "cannot stat %s", path);
     const uint64_t file_bytes = (uint64_t)st.st_size;
@@ -447,21 +446,44 @@ static int db_load_impl(lcm_handle* h, const char* path) {
     if (hd.n_frames > 0x7FFFFFFFu || sizeof hd + (uint64_t)hd.n_frames * sizeof(FrameMeta) > file_bytes)
         return fail(LCM_ERR_INVALID_ARG, "%s: header claims %u frames but the file holds %llu bytes", path, hd.n_frames,
                     (unsigned long long)file_bytes);
-    std::vector<FrameMeta> metas(hd.n_frames);
+    metas.assign(hd.n_frames, FrameMeta{});
     if (hd.n_frames && fread(metas.data(), sizeof(FrameMeta), hd.n_frames, f) != hd.n_frames)
         return fail(LCM_ERR_INVALID_ARG, "%s is truncated", path);
     uint64_t need = sizeof hd + (uint64_t)hd.n_frames * sizeof(FrameMeta);
-    uint32_t real_max_rows = 0;          // the arena is sized from the frames themselves, not from the header's claim
+    *real_max_rows = 0;                  // the arena is sized from the frames themselves, not from the header's claim
     for (size_t s = 0; s < metas.size(); ++s) {
         if (metas[s].n < 0 || (uint32_t)metas[s].n > hd.max_rows) return fail(LCM_ERR_INVALID_ARG, "%s: bad row count in frame %zu", path, s);
         if (s > 0 && metas[s].id <= metas[s - 1].id) return fail(LCM_ERR_INVALID_ARG, "%s: frame ids are not increasing", path);
         need += (uint64_t)metas[s].n * LCM_DESC_BYTES;
-        real_max_rows = std::max(real_max_rows, (uint32_t)metas[s].n);
+        *real_max_rows = std::max(*real_max_rows, (uint32_t)metas[s].n);
     }
     if (need > file_bytes) return fail(LCM_ERR_INVALID_ARG, "%s is truncated (%llu bytes, needs %llu)", path,
                                        (unsigned long long)file_bytes, (unsigned long long)need);
-    int rc = lcm_db_clear(h); if (rc) return rc;
-    rc = lcm_db_reserve(h, (int)hd.n_frames, (int)std::max<uint32_t>(real_max_rows, 1));
+    closer.keep = true;
+    *f_out = f;
+    return LCM_OK;
+}
+
+// Writes the header + frame table of a snapshot (the rows follow, frame after frame); false on an I/O error.
+bool snapshot_write_header(FILE* f, const std::vector<FrameMeta>& metas) {
+    SnapHeader hd{{'L', 'C', 'M', 'D', 'B', '0', '1', 0}, 1u, (uint32_t)metas.size(), 0u, 0u};
+    for (const FrameMeta& m : metas) hd.max_rows = std::max<uint32_t>(hd.max_rows, (uint32_t)m.n);
+    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1;
+    if (!metas.empty()) ok = ok && fwrite(metas.data(), sizeof(FrameMeta), metas.size(), f) == metas.size();
+    return ok;
+}
+}  // namespace lcm
+}  // extern "C++"
+
+static int db_load_impl(lcm_handle* h, const char* path) {
+    if (!h || !path) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    std::vector<FrameMeta> metas;
+    uint32_t real_max_rows = 0;
+    FILE* f = nullptr;
+    int rc = lcm::snapshot_open(path, metas, &real_max_rows, &f); if (rc) return rc;
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+    rc = lcm_db_clear(h); if (rc) return rc;
+    rc = lcm_db_reserve(h, (int)metas.size(), (int)std::max<uint32_t>(real_max_rows, 1));
     std::vector<uint8_t> buf((size_t)real_max_rows * LCM_DESC_BYTES + 1);
     for (size_t s = 0; !rc && s < metas.size(); ++s) {
         if (metas[s].n && fread(buf.data(), LCM_DESC_BYTES, (size_t)metas[s].n, f) != (size_t)metas[s].n) { rc = fail(LCM_ERR_INVALID_ARG, "%s: read error", path); break; }

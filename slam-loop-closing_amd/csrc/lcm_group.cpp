@@ -485,6 +485,58 @@ int lcm_group_truncate(lcm_group* g, int n_frames) {
     return LCM_OK;
 }
 
+/* Snapshot / resume of a sharded database, in lcm_db_save's OWN file format: frames are written in arrival order (each
+ * read back from the shard that owns it), so a file saved by a group of 8 loads into a single handle, a group of any
+ * other size, or the other way round.  Load validates the whole header against the file's size before the group's
+ * database is touched (lcm::snapshot_open), replaces the contents, and leaves an EMPTY group if a later step fails. */
+int lcm_group_save(lcm_group* g, const char* path) {
+    if (!g || !path) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    return guarded([&]() -> int {
+        int rc = lcm_group_sync(g); if (rc) return rc;
+        FILE* f = fopen(path, "wb");
+        if (!f) return fail(LCM_ERR_INVALID_ARG, "cannot open %s for writing", path);
+        std::vector<lcm::FrameMeta> metas(g->frames.size());
+        for (size_t i = 0; i < metas.size(); ++i) metas[i] = {g->frames[i].id, g->frames[i].n, g->frames[i].n_kp};
+        bool ok = lcm::snapshot_write_header(f, metas);
+        std::vector<uint8_t> buf;
+        const size_t W = (size_t)g->world;
+        for (size_t i = 0; ok && !rc && i < metas.size(); ++i) {
+            if (metas[i].n == 0) continue;
+            buf.resize((size_t)metas[i].n * LCM_DESC_BYTES);
+            rc = lcm_db_read(g->h[i % W], (int)(i / W), buf.data(), metas[i].n);
+            if (!rc) ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        }
+        ok = (fclose(f) == 0) && ok;
+        if (rc) return rc;
+        return ok ? LCM_OK : fail(LCM_ERR_HIP, "writing %s failed", path);
+    });
+}
+
+int lcm_group_load(lcm_group* g, const char* path) {
+    if (!g || !path) return fail(LCM_ERR_INVALID_ARG, "NULL argument");
+    return guarded([&]() -> int {
+        std::vector<lcm::FrameMeta> metas;
+        uint32_t max_rows = 0;
+        FILE* f = nullptr;
+        int rc = lcm::snapshot_open(path, metas, &max_rows, &f); if (rc) return rc;
+        struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+        rc = lcm_group_clear(g); if (rc) return rc;
+        rc = lcm_group_reserve(g, (int)metas.size(), (int)std::max<uint32_t>(max_rows, 1));
+        std::vector<uint8_t> buf((size_t)max_rows * LCM_DESC_BYTES + 1);
+        for (size_t i = 0; !rc && i < metas.size(); ++i) {
+            if (metas[i].n && fread(buf.data(), LCM_DESC_BYTES, (size_t)metas[i].n, f) != (size_t)metas[i].n) { rc = fail(LCM_ERR_INVALID_ARG, "%s: read error", path); break; }
+            rc = lcm_group_append(g, metas[i].id, buf.data(), metas[i].n, metas[i].n_kp);
+        }
+        if (!rc) rc = lcm_group_sync(g);
+        if (rc) {
+            const std::string why = lcm::last_error();
+            (void)lcm_group_clear(g);
+            lcm::last_error() = why;
+        }
+        return rc;
+    });
+}
+
 }  // extern "C"
 
 namespace {

@@ -252,6 +252,9 @@ int sync_online_streams(lcm_handle* h);   // host-wait for every query slot's ow
 int eligible_prefix(const lcm_handle* h, int query_id, int gap);   // eligible stored slots are a prefix: its length
 int pick_chunk(const lcm_handle* h, size_t total_pairs);
 int launch_and_time(lcm_handle* h, const ScoreArgs& a, uint32_t n_items, int max_q_rows, bool write_keys);
+// snapshot file helpers (lcm_db_save / _load and their group forms share ONE format)
+int snapshot_open(const char* path, std::vector<FrameMeta>& metas, uint32_t* real_max_rows, FILE** f_out);
+bool snapshot_write_header(FILE* f, const std::vector<FrameMeta>& metas);
 // ---- lcm_cross.cpp: cross_check scoring of "query c against stored slots [0, elig[c])", records in (query, slot) order
 int cross_score_prefixes(lcm_handle* h, const uint8_t* d_qbase, const uint32_t* q_row0, const int* nq, const int* elig,
                          int n_q, lcm_score* d_scores, uint32_t* d_idx_sums);

@@ -254,6 +254,45 @@ def test_truncate_single_handle(pkg, oracle):
         assert len(m) == 26 and np.array_equal(m.read_frame(25), fs.frame(25))
 
 
+def test_group_snapshot_is_the_single_handle_format(pkg, tmp_path):
+    """lcm_group_save / _load use lcm_db_save's own file format with frames in arrival order: group of 3 -> single handle
+    -> group of 5 -> group of 3, every hop with identical frames and identical search records; a corrupt file is
+    refused BEFORE the group's contents are touched."""
+    fs = pkg.synth.make_frames(41, 500, seed=77, ragged=True, dup_frac=0.3)
+    p = pkg.default_params()
+    p.min_gap = 2
+    a, b, c = str(tmp_path / "a.lcmdb"), str(tmp_path / "b.lcmdb"), str(tmp_path / "c.lcmdb")
+    with pkg.Group(p, n_devices=3, loopback_device=0) as g3, pkg.Matcher(p) as m, pkg.Group(p, n_devices=5, loopback_device=0) as g5:
+        fill(fs, g3)
+        g3.save(a)
+        m.load(a)
+        assert len(m) == 41
+        for s in (0, 17, 40):
+            assert m.frame_info(s) == (int(fs.ids[s]), int(fs.counts[s]), int(fs.counts[s]))
+            np.testing.assert_array_equal(m.read_frame(s), fs.frame(s))
+        m.save(b)
+        assert open(a, "rb").read() == open(b, "rb").read()          # one format, byte for byte
+        g5.load(b)
+        assert len(g5) == 41
+        for x, y in zip(g5.all_vs_all_argmin(), single_argmin(pkg, m)):
+            np.testing.assert_array_equal(x, y)
+        g5.save(c)
+        assert open(c, "rb").read() == open(a, "rb").read()
+        # loading replaces what the group held; appends continue behind the loaded frames
+        g3.load(c)
+        g3.append(int(fs.ids[-1]) + 1, fs.frame(0))
+        assert len(g3) == 42
+        # a truncated file: refused, the group keeps its 42 frames
+        bad = str(tmp_path / "bad.lcmdb")
+        open(bad, "wb").write(open(a, "rb").read()[:-100])
+        with pytest.raises(pkg.LcmError):
+            g3.load(bad)
+        assert len(g3) == 42
+        with pytest.raises(pkg.LcmError) as e:
+            g3.load(str(tmp_path / "missing.lcmdb"))
+        assert e.value.code == pkg.capi.ERR_NOT_FOUND and len(g3) == 42
+
+
 def test_real_multi_device_group(pkg, oracle):
     """RCCL's own transport with more than one rank: ncclAllGather of the shard arenas, grouped ncclSend / ncclRecv of the
     records and index checksums, per-device host threads.  Needs a box with >= 2 GPUs (the driver's multi-GPU node);
