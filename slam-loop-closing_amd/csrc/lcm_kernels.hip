@@ -29,21 +29,62 @@
 
 #include "lcm_kernels.h"
 
+#ifndef LCM_INNER_PRIO
+#define LCM_INNER_PRIO 1        // 0: round 1/2's (v_xor, s_nop 0, v_bcnt) order, for A/B builds (`make nop` in this directory)
+#endif
+
 namespace lcm {
 
 typedef const uint32_t __attribute__((address_space(4))) * sptr_t;   // constant AS => SMEM (s_load) when uniform
 typedef const int32_t __attribute__((address_space(4))) * siptr_t;
 
+// How the instruction stream is shaped for the gfx950 VALU (tools/order_bench, tools/prio_bench; profiles/r01_valu_class.txt,
+// r01_order_bench_*.txt, r03_prio_bench.txt, r03_valu_issue.json):
+//   * v_xor_b32 is a half-rate ("2-cycle") wave64 instruction, v_bcnt_u32_b32 / v_min3_u32 / v_lshl_or_b32 are quarter-rate
+//     ("4-cycle") ones.  A SIMD issues at most one quarter-rate instruction per quad-cycle, and it can issue a half-rate
+//     instruction of ANOTHER wave in the same quad-cycle (counter SQ_ACTIVE_INST_VALU2); one wave alone never pairs its own.
+//   * Which waves' instructions meet is the arbiter's choice, and left alone it chooses badly: every bare order of the
+//     mix costs 4.19 cycles per instruction (73 SIMD-cycles per 64 distances); rounds 1-2 put an `s_nop 0` between xor and
+//     bcnt, which let a quarter of the quad-cycles carry two instructions (54 cycles per 64 distances).
+//   * Round 3: the arbiter serves waves by PRIORITY.  Each wave raises its priority (s_setprio 3) for its popcounts and
+//     the running-minimum update, and drops it (s_setprio 0) for its xors: the quarter-rate pipe is then fed every
+//     quad-cycle from whichever waves have popcounts ready, and the other waves' xors ride in the same quad-cycles.  The
+//     8 xors per distance all but vanish from the cost: 37 SIMD-cycles per 64 distances against the 35 of the quarter-
+//     rate instructions alone (8 bcnt + 0.5 min3 + 0.27 bookkeeping, 4 cycles each) — +47 % on the whole search.
+//     Everything that is not an xor must sit in the high-priority phase: a v_min3 issued after the s_setprio 0 costs 14 %.
+//   * Two chains (the same query row against two stored rows) per phase, two temporaries; longer phases (4, 8, 16
+//     chains) and software-pipelined xors measure the same or worse.
 // One query row (8 VGPRs) against TWO train rows (16 SGPRs, rows t and t+1): both distances, both packed keys and the
 // fold into the running minimum, as ONE asm statement so that the instruction order is exactly the one below.
-//
-// Why the `s_nop 0` after every v_xor_b32: measured on gfx950 (profiles/r01_valu_class.txt, r01_order_bench_*.txt),
-// v_xor_b32 is a 2-cycle wave64 instruction and v_bcnt_u32_b32 / v_lshl_or_b32 / v_min3_u32 are 4-cycle ones, but a
-// wave that issues VALU instructions back to back holds the SIMD for 4 cycles per instruction whatever their class:
-// every order of the bare 17.5-instruction mix runs at 73-74 SIMD-cycles per 64 distances (= 17.5 x 4.19).  One
-// non-VALU instruction per (xor, bcnt) pair lets another wave take the slot and the xor then costs 2 cycles:
-// 61-63 cycles per 64 distances, +17 % throughput.  More nops (after both, or s_nop 1) are slower again.
 __device__ __forceinline__ void fold2(uint32_t& best, const uint32_t (&q)[8], const uint32_t* s, uint32_t t0, uint32_t t1) {
+#if LCM_INNER_PRIO
+    uint32_t d0, d1, x0, x1;
+    asm volatile(
+        "v_xor_b32_e32 %3, %5, %21\n\tv_xor_b32_e32 %4, %13, %21\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, 0\n\tv_bcnt_u32_b32 %2, %4, 0\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %6, %22\n\tv_xor_b32_e32 %4, %14, %22\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %7, %23\n\tv_xor_b32_e32 %4, %15, %23\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %8, %24\n\tv_xor_b32_e32 %4, %16, %24\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %9, %25\n\tv_xor_b32_e32 %4, %17, %25\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %10, %26\n\tv_xor_b32_e32 %4, %18, %26\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %11, %27\n\tv_xor_b32_e32 %4, %19, %27\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %12, %28\n\tv_xor_b32_e32 %4, %20, %28\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\t"
+        "v_lshl_or_b32 %1, %1, 22, %29\n\t"
+        "v_lshl_or_b32 %2, %2, 22, %30\n\t"
+        "v_min3_u32 %0, %0, %1, %2\n\ts_setprio 0"
+        : "+v"(best), "=&v"(d0), "=&v"(d1), "=&v"(x0), "=&v"(x1)
+        : "s"(s[0]), "s"(s[1]), "s"(s[2]), "s"(s[3]), "s"(s[4]), "s"(s[5]), "s"(s[6]), "s"(s[7]),
+          "s"(s[8]), "s"(s[9]), "s"(s[10]), "s"(s[11]), "s"(s[12]), "s"(s[13]), "s"(s[14]), "s"(s[15]),
+          "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]),
+          "s"(t0), "s"(t1));
+#else
     uint32_t d0, d1, x;
     asm volatile(
         "v_xor_b32_e32 %3, %4, %20\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, 0\n\t"
@@ -70,6 +111,7 @@ __device__ __forceinline__ void fold2(uint32_t& best, const uint32_t (&q)[8], co
           "s"(s[8]), "s"(s[9]), "s"(s[10]), "s"(s[11]), "s"(s[12]), "s"(s[13]), "s"(s[14]), "s"(s[15]),
           "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]),
           "s"(t0), "s"(t1));
+#endif
 }
 
 // Same, but only the minimum DISTANCE is tracked (no train index): what the loop search needs — a LoopCandidate
@@ -77,6 +119,31 @@ __device__ __forceinline__ void fold2(uint32_t& best, const uint32_t (&q)[8], co
 // of a detected loop comes from the pair-mode kernel on demand (README.md:101 "Re-match features on identified loop
 // frames").  Saves the two v_lshl_or_b32 per pair of distances.
 __device__ __forceinline__ void fold2_min(uint32_t& best, const uint32_t (&q)[8], const uint32_t* s) {
+#if LCM_INNER_PRIO
+    uint32_t d0, d1, x0, x1;
+    asm volatile(
+        "v_xor_b32_e32 %3, %5, %21\n\tv_xor_b32_e32 %4, %13, %21\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, 0\n\tv_bcnt_u32_b32 %2, %4, 0\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %6, %22\n\tv_xor_b32_e32 %4, %14, %22\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %7, %23\n\tv_xor_b32_e32 %4, %15, %23\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %8, %24\n\tv_xor_b32_e32 %4, %16, %24\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %9, %25\n\tv_xor_b32_e32 %4, %17, %25\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %10, %26\n\tv_xor_b32_e32 %4, %18, %26\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %11, %27\n\tv_xor_b32_e32 %4, %19, %27\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %12, %28\n\tv_xor_b32_e32 %4, %20, %28\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\t"
+        "v_min3_u32 %0, %0, %1, %2\n\ts_setprio 0"
+        : "+v"(best), "=&v"(d0), "=&v"(d1), "=&v"(x0), "=&v"(x1)
+        : "s"(s[0]), "s"(s[1]), "s"(s[2]), "s"(s[3]), "s"(s[4]), "s"(s[5]), "s"(s[6]), "s"(s[7]),
+          "s"(s[8]), "s"(s[9]), "s"(s[10]), "s"(s[11]), "s"(s[12]), "s"(s[13]), "s"(s[14]), "s"(s[15]),
+          "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
+#else
     uint32_t d0, d1, x;
     asm volatile(
         "v_xor_b32_e32 %3, %4, %20\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, 0\n\t"
@@ -100,6 +167,7 @@ __device__ __forceinline__ void fold2_min(uint32_t& best, const uint32_t (&q)[8]
         : "s"(s[0]), "s"(s[1]), "s"(s[2]), "s"(s[3]), "s"(s[4]), "s"(s[5]), "s"(s[6]), "s"(s[7]),
           "s"(s[8]), "s"(s[9]), "s"(s[10]), "s"(s[11]), "s"(s[12]), "s"(s[13]), "s"(s[14]), "s"(s[15]),
           "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
+#endif
 }
 
 // Re-scan step (ARGMIN kernels): the distance between this lane's query row and ONE train row that the lane picks
@@ -277,8 +345,14 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : (ARGMIN_MODE ==
         }
         // (dist, group) fold of this lane's running minima into its private LDS words
         auto fold_group = [&](uint32_t g) {
+#if LCM_INNER_PRIO
+            __builtin_amdgcn_s_setprio(3);       // quarter-rate packs: with the popcounts' priority (see fold2)
+#endif
 #pragma unroll
             for (int j = 0; j < QPT; ++j) atomicMin(&lane_key[j * THREADS + tid], (best[j] << KEY_SHIFT) | g);
+#if LCM_INNER_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
 
         // Train rows are stored padded to a multiple of 4 rows with copies of the LAST real row: a copy has the
@@ -420,6 +494,31 @@ __global__ __launch_bounds__(THREADS, (PACKED && QPT == 6) ? 8 : (ARGMIN_MODE ==
 // ---------------------------------------------------------------------------------------------------
 // one broadcast query row (8 VGPRs, same value in every lane) against TWO of this lane's train rows
 __device__ __forceinline__ void fold2_vv(uint32_t& best, const uint32_t (&q)[8], const uint32_t (&t0)[8], const uint32_t (&t1)[8]) {
+#if LCM_INNER_PRIO
+    uint32_t d0, d1, x0, x1;
+    asm volatile(
+        "v_xor_b32_e32 %3, %5, %13\n\tv_xor_b32_e32 %4, %5, %21\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, 0\n\tv_bcnt_u32_b32 %2, %4, 0\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %6, %14\n\tv_xor_b32_e32 %4, %6, %22\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %7, %15\n\tv_xor_b32_e32 %4, %7, %23\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %8, %16\n\tv_xor_b32_e32 %4, %8, %24\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %9, %17\n\tv_xor_b32_e32 %4, %9, %25\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %10, %18\n\tv_xor_b32_e32 %4, %10, %26\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %11, %19\n\tv_xor_b32_e32 %4, %11, %27\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %12, %20\n\tv_xor_b32_e32 %4, %12, %28\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\t"
+        "v_min3_u32 %0, %0, %1, %2\n\ts_setprio 0"
+        : "+v"(best), "=&v"(d0), "=&v"(d1), "=&v"(x0), "=&v"(x1)
+        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]),
+          "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t0[4]), "v"(t0[5]), "v"(t0[6]), "v"(t0[7]),
+          "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]), "v"(t1[4]), "v"(t1[5]), "v"(t1[6]), "v"(t1[7]));
+#else
     uint32_t d0, d1, x;
     asm volatile(
         "v_xor_b32_e32 %3, %4, %12\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, 0\n\t"
@@ -443,10 +542,39 @@ __device__ __forceinline__ void fold2_vv(uint32_t& best, const uint32_t (&q)[8],
         : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]),
           "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t0[4]), "v"(t0[5]), "v"(t0[6]), "v"(t0[7]),
           "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]), "v"(t1[4]), "v"(t1[5]), "v"(t1[6]), "v"(t1[7]));
+#endif
 }
 // same, folding packed keys dist << 22 | train row (k0, k1 = this lane's two row indices)
 __device__ __forceinline__ void fold2_vv_keys(uint32_t& best, const uint32_t (&q)[8], const uint32_t (&t0)[8], const uint32_t (&t1)[8],
                                               uint32_t k0, uint32_t k1) {
+#if LCM_INNER_PRIO
+    uint32_t d0, d1, x0, x1;
+    asm volatile(
+        "v_xor_b32_e32 %3, %5, %13\n\tv_xor_b32_e32 %4, %5, %21\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, 0\n\tv_bcnt_u32_b32 %2, %4, 0\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %6, %14\n\tv_xor_b32_e32 %4, %6, %22\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %7, %15\n\tv_xor_b32_e32 %4, %7, %23\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %8, %16\n\tv_xor_b32_e32 %4, %8, %24\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %9, %17\n\tv_xor_b32_e32 %4, %9, %25\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %10, %18\n\tv_xor_b32_e32 %4, %10, %26\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %11, %19\n\tv_xor_b32_e32 %4, %11, %27\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %12, %20\n\tv_xor_b32_e32 %4, %12, %28\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\t"
+        "v_lshl_or_b32 %1, %1, 22, %29\n\t"
+        "v_lshl_or_b32 %2, %2, 22, %30\n\t"
+        "v_min3_u32 %0, %0, %1, %2\n\ts_setprio 0"
+        : "+v"(best), "=&v"(d0), "=&v"(d1), "=&v"(x0), "=&v"(x1)
+        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]),
+          "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t0[4]), "v"(t0[5]), "v"(t0[6]), "v"(t0[7]),
+          "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]), "v"(t1[4]), "v"(t1[5]), "v"(t1[6]), "v"(t1[7]),
+          "v"(k0), "v"(k1));
+#else
     uint32_t d0, d1, x;
     asm volatile(
         "v_xor_b32_e32 %3, %4, %12\n\ts_nop 0\n\tv_bcnt_u32_b32 %1, %3, 0\n\t"
@@ -473,6 +601,7 @@ __device__ __forceinline__ void fold2_vv_keys(uint32_t& best, const uint32_t (&q
           "v"(t0[0]), "v"(t0[1]), "v"(t0[2]), "v"(t0[3]), "v"(t0[4]), "v"(t0[5]), "v"(t0[6]), "v"(t0[7]),
           "v"(t1[0]), "v"(t1[1]), "v"(t1[2]), "v"(t1[3]), "v"(t1[4]), "v"(t1[5]), "v"(t1[6]), "v"(t1[7]),
           "v"(k0), "v"(k1));
+#endif
 }
 
 template <bool ARGMIN, bool WRITE_KEYS>

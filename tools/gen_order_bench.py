@@ -122,6 +122,72 @@ VARIANTS = [
     ("N11 x s_sleep0 b", seqn("s_sleep 0")),
     ("N12 x nop2 b", seqn("s_nop 2")),
 ]
+def grouped_prio(n, hi_b=True, nop=False):
+    """n chains: n xors, s_setprio, n bcnts, s_setprio — the wave's priority differs between its xor and bcnt phases
+    (hi_b: bcnt phase at priority 3, xor phase at 0; else the other way round)"""
+    o = []
+    pb, px = ("s_setprio 3", "s_setprio 0") if hi_b else ("s_setprio 0", "s_setprio 3")
+    for g in range(0, 16, n):
+        for k in range(8):
+            for c in range(g, g + n): o.append(xor(c, k))
+            o.append(pb)
+            for i, c in enumerate(range(g, g + n)):
+                o.append(bcnt(c, k))
+                if nop and i + 1 < n: o.append("s_nop 0")
+            o.append(px)
+    return o
+def seq_alt_prio():
+    """x, s_setprio, b with the priority alternating pair by pair (one SOPP per pair, as the s_nop rule)"""
+    o = []
+    n = 0
+    for c in range(16):
+        for k in range(8):
+            o.append(xor(c, k)); o.append("s_setprio 3" if n & 1 else "s_setprio 0"); o.append(bcnt(c, k)); n += 1
+    return o
+VARIANTS += [
+    # ---- part 3 (round 3): does the wave PRIORITY steer which waves' xors share a quad-cycle?  (SQ_ACTIVE_INST_VALU2 shows
+    #      two xors of DIFFERENT waves sharing 25 % of the product kernel's quad-cycles; a wave alone never pairs its own)
+    ("P1 x prio3 b prio0", seqn("s_setprio 3", "s_setprio 0")),
+    ("P2 x prio0 b prio3", seqn("s_setprio 0", "s_setprio 3")),
+    ("P3 xx prio3 bb prio0", grouped_prio(2)),
+    ("P4 x4 prio3 b4 prio0", grouped_prio(4)),
+    ("P5 x8 prio3 b8 prio0", grouped_prio(8)),
+    ("P6 xx prio0 bb prio3", grouped_prio(2, False)),
+    ("P7 x4 prio0 b4 prio3", grouped_prio(4, False)),
+    ("P8 xx prio3 b nop b prio0", grouped_prio(2, True, True)),
+    ("P9 x4 prio3 b nop.. prio0", grouped_prio(4, True, True)),
+    ("P10 x prio(alt) b", seq_alt_prio()),
+    ("P11 x nop0 b, odd blocks prio3", seqn("s_nop 0")),
+    ("P12 x b, odd blocks prio3", seqn()),
+]
+def grouped_prio_lv(n, hi, lo, tail_hi=False, own_tail=True):
+    """grouped_prio with chosen priority levels; tail_hi: the 4-cycle pack / min ops of the tail run at the bcnt priority"""
+    o = []
+    for g in range(0, 16, n):
+        for k in range(8):
+            for c in range(g, g + n): o.append(xor(c, k))
+            o.append(f"s_setprio {hi}")
+            for c in range(g, g + n): o.append(bcnt(c, k))
+            if not (tail_hi and k == 7): o.append(f"s_setprio {lo}")
+        if tail_hi:
+            for c in range(g, g + n): o.append(f"v_lshl_or_b32 v{40 + c}, v{40 + c}, 22, %{26 + (c & 1)}")
+            for c in range(g, g + n, 2): o.append(f"v_min3_u32 v{80 + c // 2}, v{80 + c // 2}, v{40 + c}, v{41 + c}")
+            o.append(f"s_setprio {lo}")
+    return (o, True) if tail_hi else o
+def no_tail(ins):
+    return (ins, True)
+VARIANTS += [
+    # ---- part 4 (round 3): where is the floor?  (8 x 2 + 8 x 4 = 48 cycles if every xor shares its quad-cycle)
+    ("Q1 xx p3 bb p0, NO tail", no_tail(grouped_prio(2))),
+    ("Q2 x nop0 b, NO tail", no_tail(seqn("s_nop 0")[0][:16 * 8 * 3])),
+    ("Q3 xx p1 bb p0", grouped_prio_lv(2, 1, 0)),
+    ("Q4 xx p2 bb p1", grouped_prio_lv(2, 2, 1)),
+    ("Q5 xx p3 bb+tail p0", grouped_prio_lv(2, 3, 0, True)),
+    ("Q6 x4 p3 b4+tail p0", grouped_prio_lv(4, 3, 0, True)),
+    ("Q7 x8 p3 b8+tail p0", grouped_prio_lv(8, 3, 0, True)),
+    ("Q8 x16 p3 b16 p0", grouped_prio(16)),
+]
+STATIC_PRIO = {"P11 x nop0 b, odd blocks prio3", "P12 x b, odd blocks prio3"}
 def body(v):
     name, ins = v
     own_tail = False
@@ -133,10 +199,12 @@ src = ['// GENERATED by tools/gen_order_bench.py — do not edit.',
        '#include <hip/hip_runtime.h>', '#include <cstdio>', '#include <cstdint>', '#include <cstdlib>', '#include <vector>', '#include <algorithm>',
        '#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)',
        'template <int V> __global__ __launch_bounds__(256) void k(uint32_t* out, unsigned long long* clk, int iters, uint32_t seed) {',
+       '  constexpr bool STATIC_PRIO_V = ' + " || ".join(f"V == {i}" for i, v in enumerate(VARIANTS) if v[0] in STATIC_PRIO) + ';',
        '  uint32_t q[8];',
        '  for (int i = 0; i < 8; ++i) q[i] = threadIdx.x * 2654435761u + i * 40503u + seed;',
        '  uint32_t s = seed, r0v = 0, r1v = 0;',
        '  asm volatile("' + "\\n\\t".join(f"v_mov_b32 v{80 + j}, -1" for j in range(8)) + '" ::: ' + ", ".join(f'"v{80 + j}"' for j in range(8)) + ');',
+       '  if (STATIC_PRIO_V && (blockIdx.x & 1)) asm volatile("s_setprio 3");',
        '  unsigned long long t0 = 0, r0 = 0;',
        '  if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }',
        '  for (int it = 0; it < iters; ++it) {',
@@ -162,7 +230,7 @@ src += ['  }',
         '  unsigned long long* clk; CK(hipMalloc(&clk, sizeof(unsigned long long) * 2 * cus * 8)); std::vector<unsigned long long> hclk(2 * cus * 8);',
         '  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));',
         '  printf("%-26s", name);',
-        '  for (int bpc : {2, 3, 4, 5, 6}) {',
+        '  for (int bpc : {2, 3, 4, 5, 6, 7, 8}) {',
         '    const int grid = cus * bpc;',
         '    hipLaunchKernelGGL((k<V>), dim3(grid), dim3(256), 0, 0, out, clk, 50, 1u); CK(hipDeviceSynchronize());',
         '    CK(hipEventRecord(a)); hipLaunchKernelGGL((k<V>), dim3(grid), dim3(256), 0, 0, out, clk, iters, 7u); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));',
@@ -178,7 +246,8 @@ src += ['  }',
         'int main(int argc, char** argv) {',
         '  int iters = argc > 1 ? atoi(argv[1]) : 50000;',
         '  printf("SIMD-cycles per 64 distances (and chip-wide Tdist/s) at w waves per SIMD\\n");']
+src.append('  const int first = argc > 2 ? atoi(argv[2]) : 0;')
 for vi, v in enumerate(VARIANTS):
-    src.append(f'  if (run<{vi}>("{v[0]}", iters)) return 1;')
+    src.append(f'  if ({vi} >= first && run<{vi}>("{v[0]}", iters)) return 1;')
 src += ['  return 0;', '}']
 open(sys.argv[1] if len(sys.argv) > 1 else "tools/order_bench.hip", "w").write("\n".join(src) + "\n")
