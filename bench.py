@@ -37,11 +37,15 @@ sys.path.insert(0, ROOT)
 
 METRIC = "Hamming distances/sec (256-bit ORB) for all-vs-all loop search, 1/2/4/8 GPUs"
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# VALU roofline of the 16-instruction minimum (8 v_xor_b32 + 8 v_bcnt_u32_b32 per distance), from the measured
-# issue costs on gfx950 (tools/valu_peak.hip, profiles/r01_valu_peak.txt): v_xor_b32 2 cycles and v_bcnt_u32_b32
-# 4 cycles per wave64 instruction per SIMD => 48 SIMD-cycles per 64 distances; 256 CUs x 4 SIMDs at 2.4 GHz.
-VALU_PEAK_DIST_PER_S = 256 * 4 * 64 / 48.0 * 2.4e9
-VALU_NOMINAL_DIST_PER_S = 256 * 4 * 64 / 32.0 * 2.4e9      # if every one of the 16 instructions issued in 2 cycles
+# VALU roofline of the 16-instruction minimum (8 v_xor_b32 + 8 v_bcnt_u32_b32 per distance) on gfx950, from measured
+# issue behaviour (tools/valu_class.hip, tools/prio_bench; profiles/r01_valu_class.txt, r03_prio_bench.txt, r03_valu_issue.json):
+# v_bcnt_u32_b32 is a quarter-rate instruction — a SIMD issues at most one per quad-cycle — and a half-rate v_xor_b32 of
+# ANOTHER wave can issue in the same quad-cycle.  The popcounts alone therefore bound a distance: 8 quad-cycles = 32
+# SIMD-cycles per 64 distances; 256 CUs x 4 SIMDs at 2.4 GHz.
+VALU_PEAK_DIST_PER_S = 256 * 4 * 64 / 32.0 * 2.4e9
+# rounds 1-2 priced every instruction alone in its issue slot (xor 2 + bcnt 4 cycles = 48 per 64 distances): kept for
+# comparison across rounds — the priority-steered inner loop of round 3 runs ABOVE it
+VALU_SERIAL_DIST_PER_S = 256 * 4 * 64 / 48.0 * 2.4e9
 # dense matrix-core peaks (MI355X_MICROARCH.md: bf16 ~2.5 PF dense; int8 = 2x bf16 per clock, fp4 = 4x)
 MFMA_I8_PEAK_OPS = 5.0e15
 MFMA_FP4_PEAK_OPS = 10.0e15
@@ -200,20 +204,22 @@ def roofline_from_launches(pkg, infos, n_desc, argmin, traffic=None, traffic_sou
                     "hits; fold_kernels_ms_per_step sums the folds' own durations, which include waiting for a free CU behind "
                     "the other stream's score kernel"}
     valu = {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
-            "frac": kern_rate / VALU_PEAK_DIST_PER_S, "nominal_peak": VALU_NOMINAL_DIST_PER_S,
-            "nominal_frac": kern_rate / VALU_NOMINAL_DIST_PER_S,
-            "nominal_model": "all 16 instructions at the guide's 2-cycle wave64 issue on a SIMD-32 "
-                             "(v_bcnt_u32_b32 measures 4.19: tools/valu_class.hip)",
-            "model": "8 v_xor_b32 (2 cyc) + 8 v_bcnt_u32_b32 (4 cyc) per 64 distances per SIMD, 1024 SIMDs @ 2.4 GHz; "
-                     "achieved = distances per step / step_kernel_ms"}
+            "frac": kern_rate / VALU_PEAK_DIST_PER_S,
+            "model": "quarter-rate pipe: 8 v_bcnt_u32_b32 per distance, at most one per quad-cycle per SIMD (32 SIMD-cycles per 64 "
+                     "distances; the 8 half-rate v_xor_b32 issue beside them from other waves), 1024 SIMDs @ 2.4 GHz; "
+                     "achieved = distances per step / step_kernel_ms",
+            "serial_issue_peak": VALU_SERIAL_DIST_PER_S, "serial_issue_frac": kern_rate / VALU_SERIAL_DIST_PER_S,
+            "serial_issue_model": "rounds 1-2's roofline: each instruction alone in its issue slot, v_xor_b32 2 + v_bcnt_u32_b32 4 "
+                                  "cycles (48 per 64 distances); above 1.0 = xors issued beside popcounts"}
     vb = load_profile_json("valu_busy.json")
     if vb is not None:
-        valu["valu_busy_frac"] = vb.get("valu_busy_frac")
-        valu["valu_issue_slots_busy_frac"] = vb.get("valu_issue_slots_busy_frac")
-        valu["valu_busy_source"] = ("profiles/valu_busy.json (counters, NOT measured in this run): valu_busy_frac = the kernel's VALU "
-                                    "instructions priced at the issue costs the same counters give for pure v_xor_b32 / v_bcnt_u32_b32 "
-                                    "loops, over its SIMD-cycles; valu_issue_slots_busy_frac = quad-cycles with a VALU issue "
-                                    "(SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) over all quad-cycles")
+        for k in ("quarter_rate_pipe_busy_frac", "quad_cycles_with_two_valu_issued_frac", "valu_issue_slots_busy_frac", "simd_cycles_per_64_distances"):
+            valu[k] = vb.get(k)
+        valu["counters_source"] = ("profiles/valu_busy.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 GRBM_GUI_ACTIVE of this "
+                                   "command, NOT measured in this run): quarter_rate_pipe_busy_frac = the kernel's quarter-rate VALU "
+                                   "instructions (all but its 8 xors per distance) over its quad-cycles; "
+                                   "quad_cycles_with_two_valu_issued_frac = SQ_ACTIVE_INST_VALU2 over quad-cycles; "
+                                   "valu_issue_slots_busy_frac = quad-cycles with at least one VALU issue")
     return roof, valu
 
 
@@ -356,8 +362,8 @@ def stream_line(args, st, elapsed, total_dist, total_pairs, n_gpus, world, n_fra
                              "work summed over the devices, kernel time of the slowest); per-device figures; VALU-bound path, "
                              "see roofline_valu"},
         "roofline_valu": {"bound": "valu", "achieved": kern_rate, "peak": VALU_PEAK_DIST_PER_S, "unit": "distances/s",
-                          "frac": kern_rate / VALU_PEAK_DIST_PER_S, "nominal_peak": VALU_NOMINAL_DIST_PER_S,
-                          "nominal_frac": kern_rate / VALU_NOMINAL_DIST_PER_S},
+                          "frac": kern_rate / VALU_PEAK_DIST_PER_S, "serial_issue_peak": VALU_SERIAL_DIST_PER_S,
+                          "serial_issue_frac": kern_rate / VALU_SERIAL_DIST_PER_S},
         "device_busy_frac": kern_s / elapsed, "launch_time_sum_over_wall": kern_sum_s / elapsed,
         "online_streams": "one per query slot (consecutive launches overlap)" if args.online_streams else "handle's stream only",
         "cpu_baseline": cpu,
@@ -443,7 +449,7 @@ def cfg3_whole_extra(entry, pkg, torch, dev, local_rank, gap):
     out = {"workload": "cfg3 WHOLE on one GPU (BASELINE.json north_star's target shape): 10000 frames x 2000 descriptors, min_gap %d" % gap,
            "api": "lcm_all_vs_all_argmin", "seed": seed, "steps": 1, "ms_per_step": (t1 - t0) * 1e3, "pairs": int(n),
            "distances": int(li.distances), "value": int(li.distances) / (t1 - t0), "unit": "distances/s",
-           "hbm_frac": roof["frac"], "hbm_achieved_GBps": roof["achieved"], "valu_frac": valu["frac"], "valu_nominal_frac": valu["nominal_frac"],
+           "hbm_frac": roof["frac"], "hbm_achieved_GBps": roof["achieved"], "valu_frac": valu["frac"], "valu_serial_issue_frac": valu["serial_issue_frac"],
            "score_launches": int(li.score_launches), "step_kernel_ms": li.kernel_ms,
            "cpu_oracle_sample": oracle_spot_check(entry, fs, gap, offs, got, got_idx, n_pairs=200)}
     m.close()

@@ -3,8 +3,9 @@
 // so that the product kernel's VALU-busy counters can be read against known reference points:
 //   k_pure_xor   only v_xor_b32            (the 2-cycle class of profiles/r01_valu_class.txt)
 //   k_pure_bcnt  only v_bcnt_u32_b32       (the 4-cycle class)
-//   k_pair_mix   the product kernel's inner-loop body: 8 x (v_xor_b32 ; s_nop 0 ; v_bcnt_u32_b32) per distance + v_min3_u32
+//   k_pair_mix   rounds 1-2's inner-loop body: 8 x (v_xor_b32 ; s_nop 0 ; v_bcnt_u32_b32) per distance + v_min3_u32
 //                per two distances, operands in registers / SGPRs (constant "train rows"), nothing else in the loop
+//   k_prio_mix   round 3's body: the same instructions, two chains per phase, popcounts + min3 at s_setprio 3, xors at 0
 // Prints each kernel's wall time and SIMD cycles per wave64 VALU instruction at a nominal 2.4 GHz.
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -69,7 +70,36 @@ __device__ __forceinline__ void fold2_min(uint32_t& best, const uint32_t (&q)[8]
           "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
 }
 
-__global__ __launch_bounds__(256, 6) void k_pair_mix(uint32_t* out, int iters, uint32_t seed) {
+// round 3's order of the same work (lcm_kernels.hip, LCM_INNER_PRIO): two xors at priority 0, the two popcounts and the
+// minimum update at priority 3 — the other waves' half-rate xors issue beside this wave's quarter-rate popcounts
+__device__ __forceinline__ void fold2_min_prio(uint32_t& best, const uint32_t (&q)[8], const uint32_t (&s)[16]) {
+    uint32_t d0, d1, x0, x1;
+    asm volatile(
+        "v_xor_b32_e32 %3, %5, %21\n\tv_xor_b32_e32 %4, %13, %21\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, 0\n\tv_bcnt_u32_b32 %2, %4, 0\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %6, %22\n\tv_xor_b32_e32 %4, %14, %22\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %7, %23\n\tv_xor_b32_e32 %4, %15, %23\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %8, %24\n\tv_xor_b32_e32 %4, %16, %24\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %9, %25\n\tv_xor_b32_e32 %4, %17, %25\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %10, %26\n\tv_xor_b32_e32 %4, %18, %26\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %11, %27\n\tv_xor_b32_e32 %4, %19, %27\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\ts_setprio 0\n\t"
+        "v_xor_b32_e32 %3, %12, %28\n\tv_xor_b32_e32 %4, %20, %28\n\ts_setprio 3\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\t"
+        "v_min3_u32 %0, %0, %1, %2\n\ts_setprio 0"
+        : "+v"(best), "=&v"(d0), "=&v"(d1), "=&v"(x0), "=&v"(x1)
+        : "s"(s[0]), "s"(s[1]), "s"(s[2]), "s"(s[3]), "s"(s[4]), "s"(s[5]), "s"(s[6]), "s"(s[7]),
+          "s"(s[8]), "s"(s[9]), "s"(s[10]), "s"(s[11]), "s"(s[12]), "s"(s[13]), "s"(s[14]), "s"(s[15]),
+          "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
+}
+
+template <bool PRIO>
+__device__ __forceinline__ void mix_body(uint32_t* out, int iters, uint32_t seed) {
     uint32_t q[8][8], best[8], s[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -81,13 +111,16 @@ __global__ __launch_bounds__(256, 6) void k_pair_mix(uint32_t* out, int iters, u
     for (int k = 0; k < 16; ++k) s[k] = __builtin_amdgcn_readfirstlane(seed * (k + 3) + blockIdx.x);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fold2_min(best[j], q[j], s);
+        for (int j = 0; j < 8; ++j) { if (PRIO) fold2_min_prio(best[j], q[j], s); else fold2_min(best[j], q[j], s); }
     }
     uint32_t r = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r += best[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
+
+__global__ __launch_bounds__(256, 6) void k_pair_mix(uint32_t* out, int iters, uint32_t seed) { mix_body<false>(out, iters, seed); }
+__global__ __launch_bounds__(256, 6) void k_prio_mix(uint32_t* out, int iters, uint32_t seed) { mix_body<true>(out, iters, seed); }
 
 int main(int argc, char** argv) {
     const double seconds = argc > 1 ? atof(argv[1]) : 0.05;      // rough duration of each kernel
@@ -100,6 +133,7 @@ int main(int argc, char** argv) {
         {"k_pure_xor  (64 v_xor_b32 per iteration)", k_pure_xor, 8, 64.0, 2.1},
         {"k_pure_bcnt (64 v_bcnt_u32_b32 per iteration)", k_pure_bcnt, 8, 64.0, 4.2},
         {"k_pair_mix  (8 rows x [16 xor + 16 bcnt + 1 min3] per iteration)", k_pair_mix, 6, 8 * 33.0, 3.3},
+        {"k_prio_mix  (the same work, popcounts at s_setprio 3, xors at 0)", k_prio_mix, 6, 8 * 33.0, 2.3},
     };
     for (auto& k : ks) {
         const int grid = cus * k.bpc;       // 256-thread workgroups: bpc per CU = bpc waves per SIMD

@@ -51,7 +51,7 @@ ref, _ = load("valu_ref")
 prod, launches = load("valu")
 refs = {}
 for name, c in ref.items():
-    for key in ("k_pure_xor", "k_pure_bcnt", "k_pair_mix"):
+    for key in ("k_pure_xor", "k_pure_bcnt", "k_pair_mix", "k_prio_mix"):
         if key in name:
             refs[key] = derived(c)
 cost_xor = refs["k_pure_xor"]["simd_cycles_per_valu_instruction"]
@@ -67,6 +67,8 @@ if "k_pair_mix" in refs:
     pred = (16 * cost_xor + 17 * cost_bcnt) / 33.0
     refs["k_pair_mix"]["predicted_simd_cycles_per_valu_instruction"] = pred
     refs["k_pair_mix"]["valu_busy_frac"] = pred / refs["k_pair_mix"]["simd_cycles_per_valu_instruction"]
+if "k_prio_mix" in refs:
+    refs["k_prio_mix"]["serial_issue_cost_over_cycles"] = (16 * cost_xor + 17 * cost_bcnt) / 33.0 / refs["k_prio_mix"]["simd_cycles_per_valu_instruction"]
 DIST_PER_STEP = float(sys.argv[3]) if len(sys.argv) > 3 else 1.88374e12      # cfg2
 for name, c in prod.items():
     if "k_score_rowlane" not in name:
@@ -79,8 +81,10 @@ for name, c in prod.items():
     busy = n_xor * cost_xor + n_other * cost_bcnt
     d.update({"launches": launches[name], "steps": steps, "valu_instructions_per_64_distances": d["valu_instructions"] / rows64,
               "valu_busy_frac": busy / d["simd_cycles"],
-              "valu_busy_model": "8 v_xor_b32 per 64 distances at the pure-xor cost + every other VALU instruction at the pure-bcnt cost, "
-                                 "over the SIMD-cycles of the kernel (GRBM_GUI_ACTIVE / 8 x 1024)"})
+              "valu_busy_model": "SERIAL-issue pricing: 8 v_xor_b32 per 64 distances at the pure-xor cost + every other VALU instruction at "
+                                 "the pure-bcnt cost, over the SIMD-cycles of the kernel (GRBM_GUI_ACTIVE / 8 x 1024).  1.00 = the "
+                                 "instructions took as long as if each had the SIMD to itself (rounds 1-2); above 1 = half-rate "
+                                 "instructions issued BESIDE quarter-rate ones (round 3's priority-steered order)"})
     out["kernels"][name] = d
 head = [k for k in out["kernels"] if "8, 1, false, true" in k]
 if head:
@@ -93,7 +97,9 @@ if head:
 if os.path.exists(os.path.join(prof, "valu2", "p_counter_collection.csv")):
     dual = {}
     for sub in ("valu2_ref", "valu2"):
-        agg, _ = load(sub)
+        if not os.path.exists(os.path.join(prof, sub, "p_counter_collection.csv")):
+            continue
+        agg, nl = load(sub)
         for name, c in agg.items():
             if "k_score_rowlane" not in name and "k_p" not in name:
                 continue
@@ -102,17 +108,32 @@ if os.path.exists(os.path.join(prof, "valu2", "p_counter_collection.csv")):
             dual[name] = {"valu_instructions_per_quad_cycle": inst / quads, "quad_cycles_with_two_valu_issued_frac": two / quads,
                           "quad_cycles_with_a_valu_issue_frac": (inst - two) / quads,
                           "raw": {k: c[k] for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "GRBM_GUI_ACTIVE")}}
+            if "k_score_rowlane" in name:
+                # the quarter-rate pipe: every VALU instruction of the kernel except its 8 v_xor_b32 per distance is a
+                # quarter-rate one (v_bcnt_u32_b32, v_min3_u32, v_lshl_or_b32, ...: profiles/r01_valu_class.txt), and a SIMD
+                # issues at most one of those per quad-cycle
+                rows64 = DIST_PER_STEP / 64.0 * (nl[name] / 9.0)
+                slow = inst - 8.0 * rows64
+                dual[name].update({"valu_instructions_per_64_distances": inst / rows64,
+                                   "quad_cycles_per_64_distances": quads / rows64, "simd_cycles_per_64_distances": 4.0 * quads / rows64,
+                                   "quarter_rate_instructions_per_64_distances": slow / rows64,
+                                   "quarter_rate_pipe_busy_frac": slow / quads})
     out["dual_issue"] = {"counter": "SQ_ACTIVE_INST_VALU2 (gfx950: quad-cycles in which two VALU instructions are issued, per SIMD)",
                          "kernels": dual}
     for name, d in dual.items():
         if "8, 1, false, true" in name:
             out["valu_issue_slots_busy_frac"] = d["quad_cycles_with_a_valu_issue_frac"]
+            out["quad_cycles_with_two_valu_issued_frac"] = d["quad_cycles_with_two_valu_issued_frac"]
+            out["quarter_rate_pipe_busy_frac"] = d.get("quarter_rate_pipe_busy_frac")
+            out["simd_cycles_per_64_distances"] = d.get("simd_cycles_per_64_distances")
 json.dump(out, open(out_path, "w"), indent=1)
 if "dual_issue" in out:
     print("SQ_ACTIVE_INST_VALU2 (quad-cycles with two VALU instructions issued):")
     for name, d in out["dual_issue"]["kernels"].items():
-        print("  %-62s %.3f instr per quad, dual quads %.3f, quads with a VALU issue %.3f" % (
-            name[:62], d["valu_instructions_per_quad_cycle"], d["quad_cycles_with_two_valu_issued_frac"], d["quad_cycles_with_a_valu_issue_frac"]))
+        print("  %-62s %.3f instr per quad, dual quads %.3f, quads with a VALU issue %.3f%s" % (
+            name[:62], d["valu_instructions_per_quad_cycle"], d["quad_cycles_with_two_valu_issued_frac"], d["quad_cycles_with_a_valu_issue_frac"],
+            "; %.2f SIMD-cycles per 64 distances, quarter-rate pipe busy %.3f" % (d["simd_cycles_per_64_distances"], d["quarter_rate_pipe_busy_frac"])
+            if "quarter_rate_pipe_busy_frac" in d else ""))
 print("issue cost, SIMD-cycles per wave64 instruction: v_xor_b32 %.3f   v_bcnt_u32_b32 %.3f   ratio %.2f" % (cost_xor, cost_bcnt, cost_bcnt / cost_xor))
 for key, d in refs.items():
     print("  %-12s %.3f cycles per VALU instruction, %.1f active lanes, waiting to issue %.0f %% of wave-cycles%s" % (
