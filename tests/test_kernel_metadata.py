@@ -49,3 +49,35 @@ def test_no_kernel_uses_scratch_and_budgets_hold(src, tmp_path):
             if packed:                       # lane-private LDS words: 6 (8) workgroups of it must fit a CU's 160 KB
                 assert m["group_segment_fixed_size"] * (8 if qpt == 6 else 6) <= 160 * 1024, (name, m)
         assert seen >= 20
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_inner_loop_is_priority_steered(tmp_path):
+    """The headline kernel's instruction stream as the assembler emits it: every v_bcnt_u32_b32 and v_min3_u32 of the scan
+    runs between an `s_setprio 3` and the next `s_setprio 0`, every v_xor_b32 of the scan outside (the other
+    waves' half-rate xors issue beside this wave's quarter-rate popcounts — 36 instead of 54 SIMD-cycles per 64
+    distances).  A compiler or source change that moves one of them across is a 14-30 % regression no parity test sees."""
+    out = tmp_path / "lcm_kernels.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip",
+                           os.path.join(CSRC, "lcm_kernels.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    for mode in (0, 1):                                  # distance-only and argmin kernels of the packed route
+        sym = f"_ZN3lcm15k_score_rowlaneILi256ELi8ELi{mode}ELb0ELb1EEEvNS_9ScoreArgsE"
+        body = text[text.index(sym + ":"):]
+        body = body[:body.index("s_endpgm")]
+        prio, counts = 0, {"bcnt_hi": 0, "bcnt_lo": 0, "xor_hi": 0, "xor_lo": 0, "min3_hi": 0, "min3_lo": 0}
+        for line in body.splitlines():
+            ins = line.strip().split(" ")[0] if line.strip() else ""
+            if ins == "s_setprio":
+                prio = int(line.split()[1])
+            elif ins.startswith("v_bcnt_u32_b32"):
+                counts["bcnt_hi" if prio else "bcnt_lo"] += 1
+            elif ins.startswith("v_xor_b32"):
+                counts["xor_hi" if prio else "xor_lo"] += 1
+            elif ins.startswith("v_min3_u32"):
+                counts["min3_hi" if prio else "min3_lo"] += 1
+        # the scan: 2 buffers x 8 query rows x 16 (xor, bcnt) + 1 min3; the argmin re-scan (< 1 % of the work, unrolled over the
+        # 8 query rows) adds 8 x 8 xor / bcnt at low priority
+        assert counts["bcnt_hi"] == 256 and counts["xor_lo"] >= 256 and counts["min3_hi"] == 16, (mode, counts)
+        assert counts["xor_hi"] == 0 and counts["min3_lo"] == 0, (mode, counts)
+        assert counts["bcnt_lo"] <= (64 if mode == 1 else 0), (mode, counts)
