@@ -196,8 +196,8 @@ __device__ __forceinline__ uint32_t rescan_distance(const uint32_t (&q)[8], cons
 // Variants 0 / 1: row-per-lane.  ARGMIN = false tracks the best DISTANCE per query row; ARGMIN = true also finds the
 // FIRST train row that attains it (cv::BFMatcher's strict-'<' ascending scan) at the same inner-loop cost:
 //
-//   * the inner loop is the distance-only one in both cases (fold2_min: 16 x (v_xor, s_nop, v_bcnt) + v_min3 per
-//     two train rows) — no index arithmetic per distance;
+//   * the inner loop is the distance-only one in both cases (fold2_min: 8 x (2 v_xor at priority 0, 2 v_bcnt at
+//     priority 3) + v_min3 per two train rows) — no index arithmetic per distance;
 //   * every ARGMIN_GROUP (8) train rows, each lane folds `running_min << 22 | group` into a PRIVATE LDS word per
 //     query row with ds_min_u32 (1 v_lshl_or_b32 + 1 LDS atomic per 8 distances; the LDS instruction does not
 //     hold the VALU).  The running minimum never rises, so the word ends up holding (best distance, FIRST group in
