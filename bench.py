@@ -195,7 +195,7 @@ def roofline_from_launches(pkg, infos, n_desc, argmin, traffic=None, traffic_sou
             "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_step": bytes_step,
             "step_kernel_ms": step_ms, "achieved_chip": achieved * in_flight, "achieved_per_step": per_step,
             "fold_kernels_ms_per_step": fold_ms,
-            "note": "this path is VALU-bound by ~200x (0.016 algorithmic bytes per distance); see roofline_valu.  kernel_ms = "
+            "note": "this path is VALU-bound by ~100x (0.016 algorithmic bytes per distance: 8 TB/s would feed 5e14 distances/s, the quarter-rate VALU pipe issues 4.9e12); see roofline_valu.  kernel_ms = "
                     "average duration of ONE score launch (HIP events around each on its stream; with 2 launches in flight "
                     "they overlap pairwise, so the launches' durations sum to more than step_kernel_ms); achieved = bytes per "
                     "launch / kernel_ms = one launch's own rate; achieved_chip = achieved x launches in flight; "
