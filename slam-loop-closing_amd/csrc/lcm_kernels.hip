@@ -51,7 +51,7 @@ typedef const int32_t __attribute__((address_space(4))) * siptr_t;
 //     quad-cycle from whichever waves have popcounts ready, and the other waves' xors ride in the same quad-cycles.  The
 //     8 xors per distance all but vanish from the cost: 37 SIMD-cycles per 64 distances against the 35 of the quarter-
 //     rate instructions alone (8 bcnt + 0.5 min3 + 0.27 bookkeeping, 4 cycles each) — +47 % on the whole search.
-//     Everything that is not an xor must sit in the high-priority phase: a v_min3 issued after the s_setprio 0 costs 14 %.
+//     Everything that is not an xor must sit in the high-priority phase: the v_min3 issued after the s_setprio 0 cost 32 %.
 //   * Two chains (the same query row against two stored rows) per phase, two temporaries; longer phases (4, 8, 16
 //     chains) and software-pipelined xors measure the same or worse.
 // One query row (8 VGPRs) against TWO train rows (16 SGPRs, rows t and t+1): both distances, both packed keys and the

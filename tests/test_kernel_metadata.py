@@ -56,7 +56,7 @@ def test_inner_loop_is_priority_steered(tmp_path):
     """The headline kernel's instruction stream as the assembler emits it: every v_bcnt_u32_b32 and v_min3_u32 of the scan
     runs between an `s_setprio 3` and the next `s_setprio 0`, every v_xor_b32 of the scan outside (the other
     waves' half-rate xors issue beside this wave's quarter-rate popcounts — 36 instead of 54 SIMD-cycles per 64
-    distances).  A compiler or source change that moves one of them across is a 14-30 % regression no parity test sees."""
+    distances).  A compiler or source change that moves one of them across is a 15-30 % regression no parity test sees."""
     out = tmp_path / "lcm_kernels.s"
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip",
                            os.path.join(CSRC, "lcm_kernels.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
