@@ -17,8 +17,12 @@ static inline int split_chunk_rows(int qpt) { return qpt == 16 ? 512 : qpt == 32
 static int pick_online_split(const lcm_handle* h, int max_nq, size_t pairs, bool batch) {
     if (h->variant != 0 || max_nq <= 512) return 0;
     if (h->tune_online_split >= 0) return h->tune_online_split;     // lcm_set_tuning(LCM_TUNE_ONLINE_SPLIT)
-    if (batch) return pairs < 1536 ? 1 : pairs < 6144 ? 2 : pairs < lcm::ONLINE_SPLIT_MAX_PAIRS ? 4 : 0;
-    return pairs < 256 ? 1 : pairs < 3072 ? 2 : pairs < 6144 ? 4 : 0;
+    // Round 3, after the inner loop got 49 % faster (tools/online_split_sweep.py, profiles/r03_online_split_sweep.txt):
+    // 2 query rows per lane (512-row chunks, 8 waves per SIMD) is the best or within 1 % of it at every size from 48
+    // pairs up — an unsplit launch cannot finish before ONE workgroup has scanned a whole stored frame at 8 rows per
+    // lane (400 us), the 2-row pieces take 140 us — and 1 row per lane only wins below ~48 pairs (100 us).
+    if (batch) return pairs < lcm::ONLINE_SPLIT_MAX_PAIRS ? 2 : 0;
+    return pairs < 48 ? 1 : pairs < 4096 ? 2 : 0;
 }
 
 extern "C" {
